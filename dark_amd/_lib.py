@@ -1,0 +1,76 @@
+"""ctypes binding of include/dark_amd.h (dark_amd/libdark_amd.so).  No fallback: if the library is missing the
+import of anything that needs it raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libdark_amd.so")
+
+DK_OK = 0
+DK_E_ARG, DK_E_NOMEM, DK_E_HIP, DK_E_CAPACITY, DK_E_MODEL, DK_E_STREAM, DK_E_INTERNAL, DK_E_NODEVICE = -1, -2, -3, -4, -5, -6, -7, -8
+ERROR_NAMES = {-1: "DK_E_ARG", -2: "DK_E_NOMEM", -3: "DK_E_HIP", -4: "DK_E_CAPACITY", -5: "DK_E_MODEL",
+               -6: "DK_E_STREAM", -7: "DK_E_INTERNAL", -8: "DK_E_NODEVICE"}
+MODEL_IDS = {"dark": 0, "exp": 1, "ybs": 2, "simple": 3, "rawdc": 4}
+NUM_KERNEL_SLOTS = 24
+
+
+class Stats(C.Structure):
+    _fields_ = [("ms_h2d", C.c_double), ("ms_sa", C.c_double), ("ms_bwt", C.c_double), ("ms_dc", C.c_double),
+                ("ms_d2h", C.c_double), ("ms_entropy", C.c_double), ("ms_ibwt", C.c_double), ("ms_total", C.c_double),
+                ("rounds", C.c_uint32), ("sort_passes", C.c_uint32), ("sorted_elements", C.c_uint64),
+                ("dc_runs", C.c_uint64),
+                ("kernel_launches", C.c_uint32 * NUM_KERNEL_SLOTS), ("kernel_ms", C.c_double * NUM_KERNEL_SLOTS),
+                ("kernel_bytes", C.c_double * NUM_KERNEL_SLOTS)]
+
+
+# every symbol include/dark_amd.h declares: name -> (restype, argtypes)
+_vp, _sz, _szp, _u32p, _i = C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.c_int
+SIGNATURES = {
+    "dk_version": (C.c_char_p, []),
+    "dk_ctx_create": (_i, [_i, _sz, C.POINTER(_vp)]),
+    "dk_ctx_destroy": (None, [_vp]),
+    "dk_capacity": (_sz, [_vp]),
+    "dk_last_error": (C.c_char_p, [_vp]),
+    "dk_suffix_array": (_i, [_vp, _vp, _sz, _vp]),
+    "dk_bwt_forward": (_i, [_vp, _vp, _sz, _vp, _u32p]),
+    "dk_bwt_inverse": (_i, [_vp, _vp, _sz, C.c_uint32, _vp]),
+    "dk_dc_encode": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _szp]),
+    "dk_dc_decode": (_i, [_vp, _vp, _vp, _sz, _vp, _sz, _szp]),
+    "dk_block_encode": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _szp]),
+    "dk_block_decode": (_i, [_vp, _i, _vp, _sz, _sz, _vp]),
+    "dk_dev_suffix_array": (_i, [_vp, _vp, _sz, _vp]),
+    "dk_dev_bwt_forward": (_i, [_vp, _vp, _sz, _vp, _u32p]),
+    "dk_dev_bwt_inverse": (_i, [_vp, _vp, _sz, C.c_uint32, _vp]),
+    "dk_dev_dc_encode": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _szp]),
+    "dk_dev_block_encode": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _szp]),
+    "dk_dev_block_decode": (_i, [_vp, _i, _vp, _sz, _sz, _vp]),
+    "dk_model_encode": (_i, [_i, _vp, _vp, _sz, _vp, _sz, _szp]),
+    "dk_model_decode": (_i, [_i, _vp, _sz, _vp, _sz, _vp]),
+    "dk_bitcoder_encode": (_i, [_vp, _vp, _sz, _vp, _sz, _szp]),
+    "dk_bitcoder_decode": (_i, [_vp, _sz, _vp, _sz, _vp]),
+    "dk_stream_encode": (_i, [_i, _sz, _vp, _vp, _vp, _vp, _vp, _sz, C.c_uint32, _vp, _sz, _szp]),
+    "dk_stream_decode": (_i, [_i, _vp, _sz, _sz, _vp, _u32p, C.POINTER(_i)]),
+    "dk_set_profiling": (_i, [_vp, _i]),
+    "dk_stats_reset": (_i, [_vp]),
+    "dk_get_stats": (_i, [_vp, C.POINTER(Stats)]),
+    "dk_kernel_name": (C.c_char_p, [_i]),
+    "dk_dbg_sort_pairs": (_i, [_vp, _vp, _vp, _sz, _i, _i]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError("dark_amd: %s is missing -- run `python dark_amd/build.py` (hipcc, gfx950). "
+                              "There is no CPU fallback." % SO_PATH)
+        lib = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

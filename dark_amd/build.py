@@ -1,0 +1,48 @@
+"""Builds dark_amd/libdark_amd.so (HIP kernels for gfx950 + host entropy stage + C ABI) with hipcc, in-tree."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_build")
+SO = os.path.join(HERE, "libdark_amd.so")
+SOURCES = ["abi.cpp", "context.cpp", "entropy.cpp", "radix_sort.hip", "suffix_array.hip", "bwt.hip", "dc.hip"]
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "--offload-arch=" + ARCH]
+
+
+def _deps():
+    out = []
+    for root, _, files in os.walk(CSRC):
+        out += [os.path.join(root, f) for f in files]
+    out.append(os.path.join(HERE, "..", "include", "dark_amd.h"))
+    return out
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    newest_dep = max(os.path.getmtime(p) for p in _deps())
+    objs, rebuilt = [], False
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
+        objs.append(op)
+        if force or not os.path.exists(op) or os.path.getmtime(op) < newest_dep:
+            cmd = [HIPCC] + CXXFLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", sp, "-o", op]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            rebuilt = True
+    if rebuilt or not os.path.exists(SO):
+        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", SO] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print(SO)

@@ -1,0 +1,186 @@
+"""dk_ctx wrapper: one (host thread, GPU) pair owning the device workspace -- the role saca::Constructor's storage
+(src/saca.rs:344-384) and block::dc::{Encoder,Decoder}'s buffers (src/block/dc.rs:21-26,96-102) play in the reference."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class DarkError(RuntimeError):
+    def __init__(self, code, text=""):
+        self.code = code
+        super().__init__("%s (%d)%s" % (_lib.ERROR_NAMES.get(code, "error"), code, (": " + text) if text else ""))
+
+
+def _ptr(a):
+    """host numpy array or device tensor / raw int -> void*"""
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(int(a))
+
+
+def as_u8(x):
+    if isinstance(x, np.ndarray):
+        return np.ascontiguousarray(x, dtype=np.uint8)
+    return np.frombuffer(bytes(x), dtype=np.uint8)
+
+
+def model_id(m):
+    if isinstance(m, str):
+        if m not in _lib.MODEL_IDS:
+            raise DarkError(_lib.DK_E_MODEL, "unknown model %r" % m)
+        return _lib.MODEL_IDS[m]
+    return int(getattr(m, "MODEL_ID", m))
+
+
+class Context:
+    def __init__(self, max_n, device=0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        rc = self._lib.dk_ctx_create(int(device), int(max_n), C.byref(h))
+        if rc != 0:
+            raise DarkError(rc, "dk_ctx_create(device=%d, max_n=%d)" % (device, max_n))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dk_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise DarkError(rc, (self._lib.dk_last_error(self._h) or b"").decode())
+
+    def capacity(self):
+        return int(self._lib.dk_capacity(self._h))
+
+    # ---- host-pointer stage calls ----
+    def suffix_array(self, data):
+        t = as_u8(data)
+        sa = np.empty(len(t), dtype=np.uint32)
+        self._ck(self._lib.dk_suffix_array(self._h, _ptr(t), len(t), _ptr(sa)))
+        return sa
+
+    def bwt_forward(self, data):
+        t = as_u8(data)
+        out = np.empty(len(t), dtype=np.uint8)
+        origin = C.c_uint32(0)
+        self._ck(self._lib.dk_bwt_forward(self._h, _ptr(t), len(t), _ptr(out), C.byref(origin)))
+        return out, int(origin.value)
+
+    def bwt_inverse(self, bwt, origin):
+        b = as_u8(bwt)
+        out = np.empty(len(b), dtype=np.uint8)
+        self._ck(self._lib.dk_bwt_inverse(self._h, _ptr(b), len(b), int(origin), _ptr(out)))
+        return out
+
+    def dc_encode(self, bwt):
+        b = as_u8(bwt)
+        n = len(b)
+        init = np.empty(256, dtype=np.uint32)
+        d = np.empty(n, dtype=np.uint32)
+        sym = np.empty(n, dtype=np.uint8)
+        rank = np.empty(n, dtype=np.uint8)
+        m = C.c_size_t(0)
+        self._ck(self._lib.dk_dc_encode(self._h, _ptr(b), n, _ptr(init), _ptr(d), _ptr(sym), _ptr(rank), C.byref(m)))
+        m = m.value
+        return dict(init=init, d=d[:m].copy(), sym=sym[:m].copy(), rank=rank[:m].copy())
+
+    def dc_decode(self, init, d, n):
+        init = np.ascontiguousarray(init, dtype=np.uint32)
+        d = np.ascontiguousarray(d, dtype=np.uint32)
+        out = np.empty(n, dtype=np.uint8)
+        used = C.c_size_t(0)
+        self._ck(self._lib.dk_dc_decode(self._h, _ptr(init), _ptr(d), len(d), _ptr(out), n, C.byref(used)))
+        return out, used.value
+
+    def block_encode(self, model, data):
+        t = as_u8(data)
+        n = len(t)
+        mid = model_id(model)
+        cap = 10 * (n + 600) if mid == _lib.MODEL_IDS["rawdc"] else 2 * n + 4096
+        out = np.empty(cap, dtype=np.uint8)
+        ln = C.c_size_t(0)
+        self._ck(self._lib.dk_block_encode(self._h, mid, _ptr(t), n, _ptr(out), cap, C.byref(ln)))
+        return out[:ln.value].tobytes()
+
+    def block_decode(self, model, stream, n):
+        s = as_u8(stream)
+        out = np.empty(n, dtype=np.uint8)
+        self._ck(self._lib.dk_block_decode(self._h, model_id(model), _ptr(s), len(s), n, _ptr(out)))
+        return out.tobytes()
+
+    # ---- device-resident calls (torch tensors or raw device addresses) ----
+    def dev_suffix_array(self, d_in, n, d_sa_out):
+        self._ck(self._lib.dk_dev_suffix_array(self._h, _ptr(d_in), n, _ptr(d_sa_out)))
+
+    def dev_bwt_forward(self, d_in, n, d_bwt_out):
+        origin = C.c_uint32(0)
+        self._ck(self._lib.dk_dev_bwt_forward(self._h, _ptr(d_in), n, _ptr(d_bwt_out), C.byref(origin)))
+        return int(origin.value)
+
+    def dev_bwt_inverse(self, d_bwt, n, origin, d_out):
+        self._ck(self._lib.dk_dev_bwt_inverse(self._h, _ptr(d_bwt), n, int(origin), _ptr(d_out)))
+
+    def dev_dc_encode(self, d_bwt, n, d_dist, d_sym, d_rank=None):
+        init = np.empty(256, dtype=np.uint32)
+        m = C.c_size_t(0)
+        self._ck(self._lib.dk_dev_dc_encode(self._h, _ptr(d_bwt), n, _ptr(init), _ptr(d_dist), _ptr(d_sym),
+                                            _ptr(d_rank) if d_rank is not None else None, C.byref(m)))
+        return init, m.value
+
+    def dev_block_encode(self, model, d_in, n, out=None):
+        """out: optional preallocated host uint8 array; returns a view of the coded stream"""
+        mid = model_id(model)
+        if out is None:
+            out = np.empty(2 * n + 4096, dtype=np.uint8)
+        ln = C.c_size_t(0)
+        self._ck(self._lib.dk_dev_block_encode(self._h, mid, _ptr(d_in), n, _ptr(out), len(out), C.byref(ln)))
+        return out[:ln.value]
+
+    def dev_block_decode(self, model, stream, n, d_out):
+        s = as_u8(stream)
+        self._ck(self._lib.dk_dev_block_decode(self._h, model_id(model), _ptr(s), len(s), n, _ptr(d_out)))
+
+    # ---- measurement ----
+    def set_profiling(self, enabled):
+        self._ck(self._lib.dk_set_profiling(self._h, 1 if enabled else 0))
+
+    def stats_reset(self):
+        self._ck(self._lib.dk_stats_reset(self._h))
+
+    def stats(self):
+        st = _lib.Stats()
+        self._ck(self._lib.dk_get_stats(self._h, C.byref(st)))
+        out = {k: getattr(st, k) for k in ("ms_h2d", "ms_sa", "ms_bwt", "ms_dc", "ms_d2h", "ms_entropy", "ms_ibwt",
+                                           "ms_total", "rounds", "sort_passes", "sorted_elements", "dc_runs")}
+        kernels = {}
+        for i in range(_lib.NUM_KERNEL_SLOTS):
+            name = self._lib.dk_kernel_name(i)
+            if name and st.kernel_launches[i]:
+                kernels[name.decode()] = dict(launches=int(st.kernel_launches[i]), ms=float(st.kernel_ms[i]),
+                                              bytes=float(st.kernel_bytes[i]))
+        out["kernels"] = kernels
+        return out
+
+    def dbg_sort_pairs(self, keys, vals, begin_bit=0, end_bit=64):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64).copy()
+        vals = np.ascontiguousarray(vals, dtype=np.uint32).copy()
+        self._ck(self._lib.dk_dbg_sort_pairs(self._h, _ptr(keys), _ptr(vals), len(keys), begin_bit, end_bit))
+        return keys, vals

@@ -1,0 +1,447 @@
+// extern "C" boundary (include/dark_amd.h).  Thin: argument checks, workspace carving, stage sequencing, timing.
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+#include "context.hpp"
+#include "entropy.hpp"
+
+using namespace dk;
+
+namespace {
+
+int begin_call(dk_ctx *ctx) {
+    if (!ctx) return DK_E_ARG;
+    ctx->err.clear();
+    ctx->ws_reset();
+    if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(DK_E_HIP, "hipSetDevice(%d) failed", ctx->device);
+    return DK_OK;
+}
+void end_call(dk_ctx *ctx) {
+    if (ctx->profiling) ctx->prof_collect();
+}
+int check_n(dk_ctx *ctx, size_t n) {
+    if (n == 0) return ctx->fail(DK_E_ARG, "empty block (the reference panics at src/saca.rs:107)");
+    if (n > ctx->max_n) return ctx->fail(DK_E_ARG, "block of %zu bytes exceeds the context capacity %zu", n, ctx->max_n);
+    return DK_OK;
+}
+size_t workspace_bytes(size_t max_n) {
+    // text copy n + bwt n + DC arrays 10 n + SA 4 n + suffix-sort temporaries 44 n + per-tile tables (< n) + slack
+    return 64 * max_n + (48u << 20);
+}
+struct ScopedCall {
+    dk_ctx *c;
+    explicit ScopedCall(dk_ctx *ctx) : c(ctx) {}
+    ~ScopedCall() { end_call(c); }
+};
+
+// device-resident forward path up to the compact DC stream in pinned host memory
+struct ForwardResult {
+    uint32_t init[256];
+    uint32_t origin = 0;
+    size_t m = 0;
+    const uint32_t *dist = nullptr;
+    const uint8_t *sym = nullptr;
+    const uint8_t *rank = nullptr;
+    const uint32_t *run_end = nullptr;
+};
+
+int forward_to_stream(dk_ctx *ctx, const uint8_t *d_text, size_t n, bool want_ctx_fields, ForwardResult *fr) {
+    hipStream_t st = ctx->stream;
+    uint8_t *d_bwt = ctx->ws_alloc<uint8_t>(n);
+    uint32_t *d_dist = ctx->ws_alloc<uint32_t>(n);
+    uint8_t *d_sym = ctx->ws_alloc<uint8_t>(n);
+    uint8_t *d_rank = want_ctx_fields ? ctx->ws_alloc<uint8_t>(n) : nullptr;
+    uint32_t *d_run_end = want_ctx_fields ? ctx->ws_alloc<uint32_t>(n) : nullptr;
+    if (!d_bwt || !d_dist || !d_sym || (want_ctx_fields && (!d_rank || !d_run_end))) return DK_E_NOMEM;
+    {
+        const size_t mark = ctx->ws_mark();
+        uint32_t *d_sa = ctx->ws_alloc<uint32_t>(n);
+        if (!d_sa) return DK_E_NOMEM;
+        Timer t;
+        DK_TRY(suffix_array_device(ctx, d_text, n, d_sa));
+        DK_HIP(ctx, hipStreamSynchronize(st));
+        ctx->stats.ms_sa = t.ms();
+        Timer t2;
+        DK_TRY(bwt_gather_device(ctx, d_text, d_sa, n, d_bwt, &fr->origin));
+        ctx->stats.ms_bwt = t2.ms();
+        ctx->ws_release(mark);
+    }
+    Timer t3;
+    DK_TRY(dc_encode_device(ctx, d_bwt, n, fr->init, d_dist, d_sym, d_rank, d_run_end, &fr->m));
+    ctx->stats.ms_dc = t3.ms();
+    Timer t4;
+    const size_t m = fr->m;
+    const size_t off_sym = 4 * m, off_rank = off_sym + ((m + 15) & ~size_t(15)), off_end = off_rank + ((m + 15) & ~size_t(15));
+    DK_TRY(ctx->ensure_stage(off_end + 4 * m + 64));
+    DK_HIP(ctx, hipMemcpyAsync(ctx->h_stage, d_dist, 4 * m, hipMemcpyDeviceToHost, st));
+    DK_HIP(ctx, hipMemcpyAsync(ctx->h_stage + off_sym, d_sym, m, hipMemcpyDeviceToHost, st));
+    if (want_ctx_fields) {
+        DK_HIP(ctx, hipMemcpyAsync(ctx->h_stage + off_rank, d_rank, m, hipMemcpyDeviceToHost, st));
+        DK_HIP(ctx, hipMemcpyAsync(ctx->h_stage + off_end, d_run_end, 4 * m, hipMemcpyDeviceToHost, st));
+    }
+    DK_HIP(ctx, hipStreamSynchronize(st));
+    ctx->stats.ms_d2h = t4.ms();
+    fr->dist = reinterpret_cast<const uint32_t *>(ctx->h_stage);
+    fr->sym = reinterpret_cast<const uint8_t *>(ctx->h_stage + off_sym);
+    if (want_ctx_fields) {
+        fr->rank = reinterpret_cast<const uint8_t *>(ctx->h_stage + off_rank);
+        fr->run_end = reinterpret_cast<const uint32_t *>(ctx->h_stage + off_end);
+    }
+    return DK_OK;
+}
+
+int block_encode_common(dk_ctx *ctx, int model_id, const uint8_t *d_text, size_t n, uint8_t *out, size_t out_cap, size_t *out_len) {
+    if (model_max_block(model_id) == 0) return ctx->fail(DK_E_MODEL, "unknown model id %d", model_id);
+    if (n > model_max_block(model_id))
+        return ctx->fail(DK_E_MODEL, "model %d cannot code blocks of %zu bytes without losing bits (limit %llu)", model_id, n,
+                         static_cast<unsigned long long>(model_max_block(model_id)));
+    ForwardResult fr;
+    DK_TRY(forward_to_stream(ctx, d_text, n, model_id == DK_MODEL_RAWDC, &fr));
+    Timer t;
+    DcStream s;
+    s.n = n; s.init = fr.init; s.dist = fr.dist; s.sym = fr.sym; s.rank = fr.rank; s.run_end = fr.run_end; s.m = fr.m; s.origin = fr.origin;
+    int rc = encode_block_stream(model_id, s, out, out_cap, out_len);
+    ctx->stats.ms_entropy = t.ms();
+    if (rc == DK_E_CAPACITY) return ctx->fail(rc, "output buffer of %zu bytes is too small", out_cap);
+    if (rc) return ctx->fail(rc, "entropy stage failed (%d)", rc);
+    return DK_OK;
+}
+
+int block_decode_common(dk_ctx *ctx, int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *d_out) {
+    if (model_id == DK_MODEL_RAWDC || model_max_block(model_id) == 0) return ctx->fail(DK_E_MODEL, "model %d cannot decode", model_id);
+    hipStream_t st = ctx->stream;
+    DK_TRY(ctx->ensure_stage(n + 64));
+    uint8_t *h_bwt = reinterpret_cast<uint8_t *>(ctx->h_stage);
+    uint32_t origin = 0;
+    int single = 0;
+    Timer t;
+    int rc = decode_block_stream(model_id, in, in_len, n, h_bwt, &origin, &single);
+    ctx->stats.ms_entropy = t.ms();
+    if (rc) return ctx->fail(rc, "stream does not decode (corrupt, truncated, wrong model/size, or a block containing byte 0xFF, "
+                                 "which the reference format cannot represent: src/block/dc.rs:57-73)");
+    Timer t2;
+    uint8_t *d_bwt = ctx->ws_alloc<uint8_t>(n);
+    if (!d_bwt) return DK_E_NOMEM;
+    DK_HIP(ctx, hipMemcpyAsync(d_bwt, h_bwt, n, hipMemcpyHostToDevice, st));
+    ctx->stats.ms_h2d = t2.ms();
+    if (single) {
+        // One-symbol block.  The reference mis-reads origin here (it skips the one sweep distance the encoder wrote) and
+        // its bwt::decode then yields a single byte; the text is unambiguous, so return all n bytes.
+        DK_HIP(ctx, hipMemcpyAsync(d_out, d_bwt, n, hipMemcpyDeviceToDevice, st));
+        DK_HIP(ctx, hipStreamSynchronize(st));
+        return DK_OK;
+    }
+    if (origin >= n) return ctx->fail(DK_E_STREAM, "decoded origin %u is outside the block", origin);
+    Timer t3;
+    DK_TRY(bwt_inverse_device(ctx, d_bwt, n, origin, d_out));
+    ctx->stats.ms_ibwt = t3.ms();
+    return DK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *dk_version(void) { return "dark_amd 0.1 (gfx950, HIP)"; }
+
+int dk_ctx_create(int hip_device, size_t max_n, dk_ctx **out) {
+    if (!out || max_n == 0 || max_n > 0x7FFFFFFEull) return DK_E_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return DK_E_NODEVICE;
+    if (hip_device < 0 || hip_device >= count) return DK_E_NODEVICE;  // -1 would mean "CPU": there is no such backend
+    dk_ctx *c = new (std::nothrow) dk_ctx();
+    if (!c) return DK_E_NOMEM;
+    c->device = hip_device;
+    c->max_n = max_n;
+    bool ok = hipSetDevice(hip_device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    c->ws_size = workspace_bytes(max_n);
+    ok = ok && hipMalloc(reinterpret_cast<void **>(&c->ws), c->ws_size) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void **>(&c->d_mail), 1024 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&c->h_mail), 1024 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+    if (!ok) {
+        dk_ctx_destroy(c);
+        return DK_E_NOMEM;
+    }
+    *out = c;
+    return DK_OK;
+}
+
+void dk_ctx_destroy(dk_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->d_mail) (void)hipFree(c->d_mail);
+    if (c->h_mail) (void)hipHostFree(c->h_mail);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+size_t dk_capacity(const dk_ctx *ctx) { return ctx ? ctx->max_n : 0; }
+const char *dk_last_error(const dk_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+// ---- device-resident entry points ------------------------------------------------------------------------------------
+int dk_dev_suffix_array(dk_ctx *ctx, const uint8_t *d_in, size_t n, uint32_t *d_sa_out) {
+    DK_TRY(begin_call(ctx));
+    ScopedCall sc(ctx);
+    if (!d_in || !d_sa_out) return ctx->fail(DK_E_ARG, "null pointer");
+    DK_TRY(check_n(ctx, n));
+    Timer t;
+    DK_TRY(suffix_array_device(ctx, d_in, n, d_sa_out));
+    DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats.ms_sa = ctx->stats.ms_total = t.ms();
+    return DK_OK;
+}
+
+int dk_dev_bwt_forward(dk_ctx *ctx, const uint8_t *d_in, size_t n, uint8_t *d_bwt_out, uint32_t *origin) {
+    DK_TRY(begin_call(ctx));
+    ScopedCall sc(ctx);
+    if (!d_in || !d_bwt_out || !origin) return ctx->fail(DK_E_ARG, "null pointer");
+    DK_TRY(check_n(ctx, n));
+    Timer t;
+    uint32_t *d_sa = ctx->ws_alloc<uint32_t>(n);
+    if (!d_sa) return DK_E_NOMEM;
+    DK_TRY(suffix_array_device(ctx, d_in, n, d_sa));
+    DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats.ms_sa = t.ms();
+    Timer t2;
+    DK_TRY(bwt_gather_device(ctx, d_in, d_sa, n, d_bwt_out, origin));
+    ctx->stats.ms_bwt = t2.ms();
+    ctx->stats.ms_total = t.ms();
+    return DK_OK;
+}
+
+int dk_dev_bwt_inverse(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t origin, uint8_t *d_out) {
+    DK_TRY(begin_call(ctx));
+    ScopedCall sc(ctx);
+    if (!d_bwt || !d_out) return ctx->fail(DK_E_ARG, "null pointer");
+    DK_TRY(check_n(ctx, n));
+    if (origin >= n) return ctx->fail(DK_E_ARG, "origin %u outside the block of %zu bytes", origin, n);
+    Timer t;
+    DK_TRY(bwt_inverse_device(ctx, d_bwt, n, origin, d_out));
+    ctx->stats.ms_ibwt = ctx->stats.ms_total = t.ms();
+    return DK_OK;
+}
+
+int dk_dev_dc_encode(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t init[256], uint32_t *d_dist, uint8_t *d_sym, uint8_t *d_rank,
+                     size_t *m) {
+    DK_TRY(begin_call(ctx));
+    ScopedCall sc(ctx);
+    if (!d_bwt || !init || !d_dist || !d_sym || !m) return ctx->fail(DK_E_ARG, "null pointer");
+    DK_TRY(check_n(ctx, n));
+    Timer t;
+    DK_TRY(dc_encode_device(ctx, d_bwt, n, init, d_dist, d_sym, d_rank, nullptr, m));
+    ctx->stats.ms_dc = ctx->stats.ms_total = t.ms();
+    return DK_OK;
+}
+
+int dk_dev_block_encode(dk_ctx *ctx, int model_id, const uint8_t *d_in, size_t n, uint8_t *out, size_t out_cap, size_t *out_len) {
+    DK_TRY(begin_call(ctx));
+    ScopedCall sc(ctx);
+    if (!d_in || !out || !out_len) return ctx->fail(DK_E_ARG, "null pointer");
+    DK_TRY(check_n(ctx, n));
+    Timer t;
+    ctx->stats.ms_h2d = 0;
+    int rc = block_encode_common(ctx, model_id, d_in, n, out, out_cap, out_len);
+    ctx->stats.ms_total = t.ms();
+    return rc;
+}
+
+int dk_dev_block_decode(dk_ctx *ctx, int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *d_out) {
+    DK_TRY(begin_call(ctx));
+    ScopedCall sc(ctx);
+    if (!in || !d_out) return ctx->fail(DK_E_ARG, "null pointer");
+    DK_TRY(check_n(ctx, n));
+    Timer t;
+    int rc = block_decode_common(ctx, model_id, in, in_len, n, d_out);
+    ctx->stats.ms_total = t.ms();
+    return rc;
+}
+
+// ---- host-pointer entry points: stage in, run the device path, stage out ---------------------------------------------
+int dk_suffix_array(dk_ctx *ctx, const uint8_t *in, size_t n, uint32_t *sa_out) {
+    DK_TRY(begin_call(ctx));
+    ScopedCall sc(ctx);
+    if (!in || !sa_out) return ctx->fail(DK_E_ARG, "null pointer");
+    DK_TRY(check_n(ctx, n));
+    Timer t;
+    uint8_t *d_text = ctx->ws_alloc<uint8_t>(n);
+    uint32_t *d_sa = ctx->ws_alloc<uint32_t>(n);
+    if (!d_text || !d_sa) return DK_E_NOMEM;
+    DK_HIP(ctx, hipMemcpyAsync(d_text, in, n, hipMemcpyHostToDevice, ctx->stream));
+    DK_TRY(suffix_array_device(ctx, d_text, n, d_sa));
+    DK_HIP(ctx, hipMemcpyAsync(sa_out, d_sa, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats.ms_total = t.ms();
+    return DK_OK;
+}
+
+int dk_bwt_forward(dk_ctx *ctx, const uint8_t *in, size_t n, uint8_t *bwt_out, uint32_t *origin) {
+    DK_TRY(begin_call(ctx));
+    ScopedCall sc(ctx);
+    if (!in || !bwt_out || !origin) return ctx->fail(DK_E_ARG, "null pointer");
+    DK_TRY(check_n(ctx, n));
+    Timer t;
+    uint8_t *d_text = ctx->ws_alloc<uint8_t>(n);
+    uint8_t *d_bwt = ctx->ws_alloc<uint8_t>(n);
+    uint32_t *d_sa = ctx->ws_alloc<uint32_t>(n);
+    if (!d_text || !d_bwt || !d_sa) return DK_E_NOMEM;
+    DK_HIP(ctx, hipMemcpyAsync(d_text, in, n, hipMemcpyHostToDevice, ctx->stream));
+    DK_TRY(suffix_array_device(ctx, d_text, n, d_sa));
+    DK_TRY(bwt_gather_device(ctx, d_text, d_sa, n, d_bwt, origin));
+    DK_HIP(ctx, hipMemcpyAsync(bwt_out, d_bwt, n, hipMemcpyDeviceToHost, ctx->stream));
+    DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats.ms_total = t.ms();
+    return DK_OK;
+}
+
+int dk_bwt_inverse(dk_ctx *ctx, const uint8_t *bwt, size_t n, uint32_t origin, uint8_t *out) {
+    DK_TRY(begin_call(ctx));
+    ScopedCall sc(ctx);
+    if (!bwt || !out) return ctx->fail(DK_E_ARG, "null pointer");
+    DK_TRY(check_n(ctx, n));
+    if (origin >= n) return ctx->fail(DK_E_ARG, "origin %u outside the block of %zu bytes", origin, n);
+    Timer t;
+    uint8_t *d_bwt = ctx->ws_alloc<uint8_t>(n);
+    uint8_t *d_out = ctx->ws_alloc<uint8_t>(n);
+    if (!d_bwt || !d_out) return DK_E_NOMEM;
+    DK_HIP(ctx, hipMemcpyAsync(d_bwt, bwt, n, hipMemcpyHostToDevice, ctx->stream));
+    DK_TRY(bwt_inverse_device(ctx, d_bwt, n, origin, d_out));
+    DK_HIP(ctx, hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, ctx->stream));
+    DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats.ms_total = t.ms();
+    return DK_OK;
+}
+
+int dk_dc_encode(dk_ctx *ctx, const uint8_t *bwt, size_t n, uint32_t init[256], uint32_t *dist, uint8_t *sym, uint8_t *rank, size_t *m) {
+    DK_TRY(begin_call(ctx));
+    ScopedCall sc(ctx);
+    if (!bwt || !init || !dist || !sym || !m) return ctx->fail(DK_E_ARG, "null pointer");
+    DK_TRY(check_n(ctx, n));
+    Timer t;
+    uint8_t *d_bwt = ctx->ws_alloc<uint8_t>(n);
+    uint32_t *d_dist = ctx->ws_alloc<uint32_t>(n);
+    uint8_t *d_sym = ctx->ws_alloc<uint8_t>(n);
+    uint8_t *d_rank = ctx->ws_alloc<uint8_t>(n);
+    if (!d_bwt || !d_dist || !d_sym || !d_rank) return DK_E_NOMEM;
+    DK_HIP(ctx, hipMemcpyAsync(d_bwt, bwt, n, hipMemcpyHostToDevice, ctx->stream));
+    DK_TRY(dc_encode_device(ctx, d_bwt, n, init, d_dist, d_sym, d_rank, nullptr, m));
+    DK_HIP(ctx, hipMemcpyAsync(dist, d_dist, *m * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    DK_HIP(ctx, hipMemcpyAsync(sym, d_sym, *m, hipMemcpyDeviceToHost, ctx->stream));
+    if (rank) DK_HIP(ctx, hipMemcpyAsync(rank, d_rank, *m, hipMemcpyDeviceToHost, ctx->stream));
+    DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats.ms_total = t.ms();
+    return DK_OK;
+}
+
+int dk_dc_decode(dk_ctx *ctx, const uint32_t init[256], const uint32_t *dist, size_t m, uint8_t *bwt_out, size_t n, size_t *consumed) {
+    if (!init || (!dist && m) || !bwt_out || n == 0) return ctx ? ctx->fail(DK_E_ARG, "null pointer or empty block") : DK_E_ARG;
+    int rc = dc_decode_array(init, dist, m, bwt_out, n, consumed);
+    if (rc && ctx) return ctx->fail(rc, "distance stream does not rebuild a BWT of %zu bytes", n);
+    return rc;
+}
+
+int dk_block_encode(dk_ctx *ctx, int model_id, const uint8_t *in, size_t n, uint8_t *out, size_t out_cap, size_t *out_len) {
+    DK_TRY(begin_call(ctx));
+    ScopedCall sc(ctx);
+    if (!in || !out || !out_len) return ctx->fail(DK_E_ARG, "null pointer");
+    DK_TRY(check_n(ctx, n));
+    Timer t;
+    uint8_t *d_text = ctx->ws_alloc<uint8_t>(n);
+    if (!d_text) return DK_E_NOMEM;
+    DK_HIP(ctx, hipMemcpyAsync(d_text, in, n, hipMemcpyHostToDevice, ctx->stream));
+    DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats.ms_h2d = t.ms();
+    int rc = block_encode_common(ctx, model_id, d_text, n, out, out_cap, out_len);
+    ctx->stats.ms_total = t.ms();
+    return rc;
+}
+
+int dk_block_decode(dk_ctx *ctx, int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *out) {
+    DK_TRY(begin_call(ctx));
+    ScopedCall sc(ctx);
+    if (!in || !out) return ctx->fail(DK_E_ARG, "null pointer");
+    DK_TRY(check_n(ctx, n));
+    Timer t;
+    uint8_t *d_out = ctx->ws_alloc<uint8_t>(n);
+    if (!d_out) return DK_E_NOMEM;
+    DK_TRY(block_decode_common(ctx, model_id, in, in_len, n, d_out));
+    Timer t2;
+    DK_HIP(ctx, hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, ctx->stream));
+    DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats.ms_d2h = t2.ms();
+    ctx->stats.ms_total = t.ms();
+    return DK_OK;
+}
+
+// ---- model / coder level (host only) --------------------------------------------------------------------------------------
+int dk_model_encode(int model_id, const uint32_t *dist, const uint8_t *sym, size_t m, uint8_t *out, size_t out_cap, size_t *out_len) {
+    if ((!dist || !sym) && m) return DK_E_ARG;
+    if (!out || !out_len) return DK_E_ARG;
+    return model_encode_stream(model_id, dist, sym, m, out, out_cap, out_len);
+}
+int dk_model_decode(int model_id, const uint8_t *in, size_t in_len, const uint8_t *sym, size_t m, uint32_t *dist) {
+    if (!in || ((!sym || !dist) && m)) return DK_E_ARG;
+    return model_decode_stream(model_id, in, in_len, sym, m, dist);
+}
+int dk_bitcoder_encode(const uint8_t *bits, const uint16_t *flat, size_t nbits, uint8_t *out, size_t out_cap, size_t *out_len) {
+    if (((!bits || !flat) && nbits) || !out || !out_len) return DK_E_ARG;
+    return bitcoder_encode(bits, flat, nbits, out, out_cap, out_len);
+}
+int dk_bitcoder_decode(const uint8_t *in, size_t in_len, const uint16_t *flat, size_t nbits, uint8_t *bits) {
+    if (!in || ((!flat || !bits) && nbits)) return DK_E_ARG;
+    return bitcoder_decode(in, in_len, flat, nbits, bits);
+}
+int dk_stream_encode(int model_id, size_t n, const uint32_t init[256], const uint32_t *dist, const uint8_t *sym, const uint8_t *rank,
+                     const uint32_t *run_end, size_t m, uint32_t origin, uint8_t *out, size_t out_cap, size_t *out_len) {
+    DcStream s;
+    s.n = n; s.init = init; s.dist = dist; s.sym = sym; s.rank = rank; s.run_end = run_end; s.m = m; s.origin = origin;
+    return encode_block_stream(model_id, s, out, out_cap, out_len);
+}
+int dk_stream_decode(int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *bwt_out, uint32_t *origin, int *single_symbol) {
+    int single = 0;
+    int rc = decode_block_stream(model_id, in, in_len, n, bwt_out, origin, &single);
+    if (single_symbol) *single_symbol = single;
+    return rc;
+}
+
+// ---- measurement ----------------------------------------------------------------------------------------------------------
+int dk_set_profiling(dk_ctx *ctx, int enabled) {
+    if (!ctx) return DK_E_ARG;
+    ctx->profiling = enabled != 0;
+    return DK_OK;
+}
+int dk_stats_reset(dk_ctx *ctx) {
+    if (!ctx) return DK_E_ARG;
+    ctx->stats = dk_stats{};
+    return DK_OK;
+}
+int dk_get_stats(const dk_ctx *ctx, dk_stats *out) {
+    if (!ctx || !out) return DK_E_ARG;
+    *out = ctx->stats;
+    return DK_OK;
+}
+const char *dk_kernel_name(int slot) { return kernel_slot_name(slot); }
+
+// ---- debug ------------------------------------------------------------------------------------------------------------------
+int dk_dbg_sort_pairs(dk_ctx *ctx, uint64_t *keys, uint32_t *vals, size_t count, int begin_bit, int end_bit) {
+    DK_TRY(begin_call(ctx));
+    ScopedCall sc(ctx);
+    if (!keys || !vals || count == 0) return ctx->fail(DK_E_ARG, "null pointer or empty input");
+    uint64_t *k0 = ctx->ws_alloc<uint64_t>(count), *k1 = ctx->ws_alloc<uint64_t>(count);
+    uint32_t *v0 = ctx->ws_alloc<uint32_t>(count), *v1 = ctx->ws_alloc<uint32_t>(count);
+    if (!k0 || !k1 || !v0 || !v1) return DK_E_NOMEM;
+    DK_HIP(ctx, hipMemcpyAsync(k0, keys, count * 8, hipMemcpyHostToDevice, ctx->stream));
+    DK_HIP(ctx, hipMemcpyAsync(v0, vals, count * 4, hipMemcpyHostToDevice, ctx->stream));
+    DK_TRY(sort_pairs(ctx, k0, k1, v0, v1, count, begin_bit, end_bit));
+    DK_HIP(ctx, hipMemcpyAsync(keys, k0, count * 8, hipMemcpyDeviceToHost, ctx->stream));
+    DK_HIP(ctx, hipMemcpyAsync(vals, v0, count * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DK_OK;
+}
+
+}  // extern "C"

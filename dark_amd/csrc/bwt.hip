@@ -1,0 +1,324 @@
+// Forward BWT emit and inverse BWT.
+//
+// Forward: replaces compress::bwt::TransformIterator as driven by src/block/dc.rs:45-50 (known answers
+// src/saca.rs:411-412): L[j] = T[SA[j]-1], L[j] = T[n-1] where SA[j] == 0, origin = that j.
+//
+// Inverse: replaces compress::bwt::decode as driven by src/block/dc.rs:154-156 (in-repo analogue
+// etc/dark-c/src/archon3.cpp:70-86).  The serial "follow the jump table n times" becomes
+//   k_ibwt_hist / scan   per-tile symbol histograms -> stable counting-sort offsets (one 8-bit radix pass over L)
+//   k_ibwt_lf            psi[LF(i)] = i, with the origin element placed first in its symbol class (same rule as
+//                        the reference's table build), psi[class start of L[origin]] = END
+//   k_ibwt_walk          every position that is a multiple of S (plus origin) is a splitter; one lane per splitter
+//                        walks psi to the next splitter and records (next splitter, steps)
+//   k_ibwt_rank          pointer jumping over the reduced list -> text offset of every splitter
+//   k_ibwt_emit          one lane per splitter re-walks its sub-list and writes the text bytes
+#include "context.hpp"
+#include "device_util.hpp"
+
+namespace dk {
+namespace {
+
+// ---- forward ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bwt_gather(const uint8_t *__restrict__ t, const uint32_t *__restrict__ sa, size_t n,
+                                                     uint8_t *__restrict__ bwt, uint32_t *__restrict__ origin) {
+    // 4 outputs per thread so that the byte stores leave as one dword
+    const size_t j0 = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 4;
+    if (j0 >= n) return;
+    uint32_t packed = 0;
+    const int cnt = n - j0 < 4 ? static_cast<int>(n - j0) : 4;
+    for (int k = 0; k < cnt; ++k) {
+        const uint32_t p = sa[j0 + k];
+        uint8_t c;
+        if (p == 0) {
+            c = t[n - 1];
+            *origin = static_cast<uint32_t>(j0 + k);
+        } else {
+            c = t[p - 1];
+        }
+        packed |= static_cast<uint32_t>(c) << (8 * k);
+    }
+    if (cnt == 4 && (reinterpret_cast<uintptr_t>(bwt) & 3) == 0) {
+        *reinterpret_cast<uint32_t *>(bwt + j0) = packed;
+    } else {
+        for (int k = 0; k < cnt; ++k) bwt[j0 + k] = static_cast<uint8_t>(packed >> (8 * k));
+    }
+}
+
+// ---- inverse ------------------------------------------------------------------------------------------------------
+constexpr uint32_t IB_END = 0xFFFFFFFFu;
+constexpr int IB_BLOCK = 256;
+constexpr int IB_WAVES = IB_BLOCK / 64;
+constexpr int IB_SPT = 16;                    // symbols per thread
+constexpr int IB_TILE = IB_BLOCK * IB_SPT;    // 4096 symbols per workgroup
+constexpr int IB_MAX_CHUNKS = 256;
+
+__global__ __launch_bounds__(IB_BLOCK) void k_ibwt_hist(const uint8_t *__restrict__ bwt, size_t n, uint32_t *__restrict__ tile_hist) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t base = static_cast<size_t>(blockIdx.x) * IB_TILE;
+#pragma unroll
+    for (int k = 0; k < IB_SPT; ++k) {
+        const size_t i = base + static_cast<size_t>(k) * IB_BLOCK + threadIdx.x;
+        if (i < n) atomicAdd(&h[bwt[i]], 1u);
+    }
+    __syncthreads();
+    tile_hist[static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x] = h[threadIdx.x];
+}
+// digit-major exclusive scan of tile_hist, same three phases as the radix sort; class_start[256] also exported
+__global__ __launch_bounds__(256) void k_ibwt_scan_a(const uint32_t *__restrict__ tile_hist, size_t ntiles, size_t tpc,
+                                                      uint32_t *__restrict__ chunk_sum) {
+    const size_t g = blockIdx.x, t0 = g * tpc, t1 = t0 + tpc < ntiles ? t0 + tpc : ntiles;
+    uint32_t s = 0;
+#pragma unroll 8
+    for (size_t t = t0; t < t1; ++t) s += tile_hist[t * 256 + threadIdx.x];
+    chunk_sum[g * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_ibwt_scan_b(uint32_t *__restrict__ chunk_sum, size_t nchunks, uint32_t *__restrict__ class_start) {
+    __shared__ uint32_t s_tmp[IB_WAVES + 1];
+    const int d = threadIdx.x;
+    uint32_t run = 0;
+#pragma unroll 8
+    for (size_t g = 0; g < nchunks; ++g) {
+        const uint32_t v = chunk_sum[g * 256 + d];
+        chunk_sum[g * 256 + d] = run;
+        run += v;
+    }
+    const uint32_t base = block_excl_sum<IB_WAVES>(run, s_tmp, nullptr);
+    class_start[d] = base;
+#pragma unroll 8
+    for (size_t g = 0; g < nchunks; ++g) chunk_sum[g * 256 + d] += base;
+}
+__global__ __launch_bounds__(256) void k_ibwt_scan_c(uint32_t *__restrict__ tile_hist, size_t ntiles, size_t tpc,
+                                                      const uint32_t *__restrict__ chunk_sum) {
+    const size_t g = blockIdx.x, t0 = g * tpc, t1 = t0 + tpc < ntiles ? t0 + tpc : ntiles;
+    uint32_t run = chunk_sum[g * 256 + threadIdx.x];
+    for (size_t t = t0; t < t1; ++t) {
+        const uint32_t v = tile_hist[t * 256 + threadIdx.x];
+        tile_hist[t * 256 + threadIdx.x] = run;
+        run += v;
+    }
+}
+
+// psi[LF(i)] = i.  LF is the stable counting-sort destination of L[i], except that the origin element goes first in
+// its class (it is the suffix consisting of the last text symbol alone, the smallest of its class).
+__global__ __launch_bounds__(IB_BLOCK) void k_ibwt_lf(const uint8_t *__restrict__ bwt, size_t n, uint32_t origin,
+                                                       const uint32_t *__restrict__ tile_offs, const uint32_t *__restrict__ class_start,
+                                                       uint32_t *__restrict__ psi) {
+    __shared__ uint32_t s_cnt[IB_WAVES][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t tile_base = static_cast<size_t>(blockIdx.x) * IB_TILE;
+    for (int i = tid; i < IB_WAVES * 256; i += IB_BLOCK) (&s_cnt[0][0])[i] = 0;
+    const uint32_t wbase = static_cast<uint32_t>(wave) * (64 * IB_SPT);
+    uint32_t sym[IB_SPT], rnk[IB_SPT];
+#pragma unroll
+    for (int k = 0; k < IB_SPT; ++k) {
+        const size_t i = tile_base + wbase + k * 64 + lane;
+        sym[k] = i < n ? bwt[i] : 0x100u;  // 0x100 = padding, ranked but never stored
+    }
+    __syncthreads();
+    const uint64_t lt = lanemask_lt(lane);
+#pragma unroll
+    for (int k = 0; k < IB_SPT; ++k) {
+        const uint32_t d = sym[k] & 0xFFu;
+        const bool pad = sym[k] > 0xFFu;
+        uint64_t same = __ballot(!pad);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            same &= bit ? bal : ~bal;
+        }
+        const uint32_t before = static_cast<uint32_t>(__popcll(same & lt));
+        const uint32_t old = pad ? 0u : s_cnt[wave][d];
+        __builtin_amdgcn_wave_barrier();
+        if (!pad && before == 0) s_cnt[wave][d] = old + static_cast<uint32_t>(__popcll(same));
+        __builtin_amdgcn_wave_barrier();
+        rnk[k] = old + before;
+    }
+    __syncthreads();
+    {
+        const int d = tid;
+        uint32_t run = tile_offs[static_cast<size_t>(blockIdx.x) * 256 + d];
+#pragma unroll
+        for (int w = 0; w < IB_WAVES; ++w) {
+            const uint32_t c = s_cnt[w][d];
+            s_cnt[w][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    const uint32_t c0 = bwt[origin];
+    const uint32_t c0_start = class_start[c0];
+#pragma unroll
+    for (int k = 0; k < IB_SPT; ++k) {
+        const size_t i = tile_base + wbase + k * 64 + lane;
+        if (i >= n) continue;
+        uint32_t dest = s_cnt[wave][sym[k]] + rnk[k];
+        if (i == origin) dest = c0_start;
+        else if (sym[k] == c0 && i < origin) dest += 1;
+        // the origin element has no successor: following it ends the text (the reference stores table[..] = 0 there)
+        psi[dest] = i == origin ? IB_END : static_cast<uint32_t>(i);
+    }
+}
+
+// Splitters: positions that are multiples of S, and origin (the start of the text).  Splitter id of position p:
+// p / S for p % S == 0; id nsplit-1 is reserved for origin when origin is not a multiple of S.
+__device__ __forceinline__ bool is_splitter(uint32_t p, uint32_t S, uint32_t origin) { return (p % S) == 0 || p == origin; }
+__device__ __forceinline__ uint32_t splitter_id(uint32_t p, uint32_t S, uint32_t origin, uint32_t nreg) {
+    return (p == origin && (p % S) != 0) ? nreg : p / S;
+}
+
+// Text step k visits position cur_k: cur_0 = origin, cur_{k+1} = psi[cur_k]... with the reference's convention the
+// text symbol k is L[psi[cur_k]], and the last symbol is L[origin] when psi hits END.
+__global__ __launch_bounds__(256) void k_ibwt_walk(const uint32_t *__restrict__ psi, uint32_t n, uint32_t origin, uint32_t S,
+                                                    uint32_t nreg, uint32_t nsplit, uint32_t *__restrict__ nxt,
+                                                    uint32_t *__restrict__ len) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsplit) return;
+    uint32_t cur;
+    if (s == nreg) {
+        cur = origin;  // only exists when origin % S != 0
+    } else {
+        cur = s * S;
+        if (cur >= n) { nxt[s] = IB_END; len[s] = 0; return; }
+    }
+    uint32_t steps = 0, to = IB_END;
+    for (;;) {
+        const uint32_t p = psi[cur];
+        ++steps;  // this step emits one text symbol
+        if (p == IB_END) break;
+        if (is_splitter(p, S, origin)) { to = splitter_id(p, S, origin, nreg); break; }
+        cur = p;
+        if (steps > n) break;  // corrupt input: never spin
+    }
+    nxt[s] = to;
+    len[s] = steps;
+}
+
+// pointer jumping: dist_to_end[s] = len[s] + dist_to_end[nxt[s]]
+__global__ __launch_bounds__(256) void k_ibwt_jump(const uint32_t *__restrict__ nxt_in, const uint32_t *__restrict__ acc_in,
+                                                    uint32_t *__restrict__ nxt_out, uint32_t *__restrict__ acc_out, uint32_t nsplit,
+                                                    uint32_t *__restrict__ pending) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsplit) return;
+    const uint32_t to = nxt_in[s];
+    uint32_t a = acc_in[s];
+    if (to == IB_END) {
+        nxt_out[s] = IB_END;
+        acc_out[s] = a;
+        return;
+    }
+    a += acc_in[to];
+    const uint32_t to2 = nxt_in[to];
+    nxt_out[s] = to2;
+    acc_out[s] = a;
+    if (to2 != IB_END) *pending = 1;
+}
+
+__global__ __launch_bounds__(256) void k_ibwt_emit(const uint8_t *__restrict__ bwt, const uint32_t *__restrict__ psi, uint32_t n,
+                                                    uint32_t origin, uint32_t S, uint32_t nreg, uint32_t nsplit,
+                                                    const uint32_t *__restrict__ dist_to_end, uint8_t *__restrict__ out,
+                                                    uint32_t *__restrict__ bad) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsplit) return;
+    uint32_t cur;
+    if (s == nreg) cur = origin;
+    else { cur = s * S; if (cur >= n) return; }
+    const uint32_t d = dist_to_end[s];
+    if (d > n) { *bad = 1; return; }  // not on the text cycle (corrupt input)
+    uint32_t k = n - d;  // text offset of the first symbol this splitter emits
+    for (;;) {
+        const uint32_t p = psi[cur];
+        if (p == IB_END) { if (k < n) out[k] = bwt[origin]; else *bad = 1; break; }
+        if (k >= n) { *bad = 1; break; }
+        out[k++] = bwt[p];
+        if (is_splitter(p, S, origin)) break;
+        cur = p;
+    }
+}
+
+}  // namespace
+
+int bwt_gather_device(dk_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, size_t n, uint8_t *d_bwt, uint32_t *origin) {
+    hipStream_t st = ctx->stream;
+    uint32_t *d_origin = ctx->d_mail + 8;
+    DK_HIP(ctx, hipMemsetAsync(d_origin, 0xFF, sizeof(uint32_t), st));
+    {
+        LaunchScope ls(ctx, K_BWT_GATHER, 6.0 * n);
+        k_bwt_gather<<<dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, st>>>(d_text, d_sa, n, d_bwt, d_origin);
+    }
+    DK_HIP(ctx, hipGetLastError());
+    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 8, d_origin, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    DK_HIP(ctx, hipStreamSynchronize(st));
+    *origin = ctx->h_mail[8];
+    if (*origin >= n) return ctx->fail(DK_E_INTERNAL, "bwt_forward: no suffix 0 in the suffix array");
+    return DK_OK;
+}
+
+int bwt_inverse_device(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t origin, uint8_t *d_out) {
+    if (n == 0 || n > 0xFFFFFFF0ull || origin >= n) return ctx->fail(DK_E_ARG, "bwt_inverse: bad n / origin");
+    hipStream_t st = ctx->stream;
+    const size_t mark = ctx->ws_mark();
+    const size_t ntiles = div_up(n, IB_TILE);
+    const size_t tpc = div_up(ntiles, IB_MAX_CHUNKS);
+    const size_t nchunks = div_up(ntiles, tpc);
+    uint32_t *tile_hist = ctx->ws_alloc<uint32_t>(ntiles * 256);
+    uint32_t *chunk_sum = ctx->ws_alloc<uint32_t>(nchunks * 256);
+    uint32_t *class_start = ctx->ws_alloc<uint32_t>(256);
+    uint32_t *psi = ctx->ws_alloc<uint32_t>(n);
+    if (!tile_hist || !chunk_sum || !class_start || !psi) return DK_E_NOMEM;
+    {
+        LaunchScope ls(ctx, K_IBWT_HIST, 1.0 * n);
+        k_ibwt_hist<<<dim3(ntiles), dim3(IB_BLOCK), 0, st>>>(d_bwt, n, tile_hist);
+        k_ibwt_scan_a<<<dim3(nchunks), dim3(256), 0, st>>>(tile_hist, ntiles, tpc, chunk_sum);
+        k_ibwt_scan_b<<<dim3(1), dim3(256), 0, st>>>(chunk_sum, nchunks, class_start);
+        k_ibwt_scan_c<<<dim3(nchunks), dim3(256), 0, st>>>(tile_hist, ntiles, tpc, chunk_sum);
+    }
+    {
+        LaunchScope ls(ctx, K_IBWT_LF, 5.0 * n);
+        k_ibwt_lf<<<dim3(ntiles), dim3(IB_BLOCK), 0, st>>>(d_bwt, n, origin, tile_hist, class_start, psi);
+    }
+    DK_HIP(ctx, hipGetLastError());
+    // splitters
+    const uint32_t S = n < (1u << 16) ? 8u : 32u;
+    const uint32_t nreg = static_cast<uint32_t>(div_up(n, S));
+    const uint32_t nsplit = nreg + ((origin % S) != 0 ? 1u : 0u);
+    uint32_t *nxt = ctx->ws_alloc<uint32_t>(nsplit), *nxt_alt = ctx->ws_alloc<uint32_t>(nsplit);
+    uint32_t *acc = ctx->ws_alloc<uint32_t>(nsplit), *acc_alt = ctx->ws_alloc<uint32_t>(nsplit);
+    if (!nxt || !nxt_alt || !acc || !acc_alt) return DK_E_NOMEM;
+    {
+        LaunchScope ls(ctx, K_IBWT_WALK, 4.0 * n);
+        k_ibwt_walk<<<dim3(div_up(nsplit, 256)), dim3(256), 0, st>>>(psi, static_cast<uint32_t>(n), origin, S, nreg, nsplit, nxt, acc);
+    }
+    DK_HIP(ctx, hipGetLastError());
+    uint32_t *d_pending = ctx->d_mail + 10;
+    for (int it = 0; it < 40; ++it) {
+        DK_HIP(ctx, hipMemsetAsync(d_pending, 0, sizeof(uint32_t), st));
+        {
+            LaunchScope ls(ctx, K_IBWT_RANK, 24.0 * nsplit);
+            k_ibwt_jump<<<dim3(div_up(nsplit, 256)), dim3(256), 0, st>>>(nxt, acc, nxt_alt, acc_alt, nsplit, d_pending);
+        }
+        std::swap(nxt, nxt_alt);
+        std::swap(acc, acc_alt);
+        DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 10, d_pending, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        DK_HIP(ctx, hipStreamSynchronize(st));
+        if (ctx->h_mail[10] == 0) break;
+        if (it == 39) return ctx->fail(DK_E_STREAM, "bwt_inverse: successor table has a cycle (corrupt input)");
+    }
+    uint32_t *d_bad = ctx->d_mail + 11;
+    DK_HIP(ctx, hipMemsetAsync(d_bad, 0, sizeof(uint32_t), st));
+    {
+        LaunchScope ls(ctx, K_IBWT_EMIT, 6.0 * n);
+        k_ibwt_emit<<<dim3(div_up(nsplit, 256)), dim3(256), 0, st>>>(d_bwt, psi, static_cast<uint32_t>(n), origin, S, nreg, nsplit, acc,
+                                                                      d_out, d_bad);
+    }
+    DK_HIP(ctx, hipGetLastError());
+    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 11, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    DK_HIP(ctx, hipStreamSynchronize(st));
+    ctx->ws_release(mark);
+    if (ctx->h_mail[11]) return ctx->fail(DK_E_STREAM, "bwt_inverse: BWT/origin do not describe a single text cycle");
+    return DK_OK;
+}
+
+}  // namespace dk

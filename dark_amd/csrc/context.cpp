@@ -1,0 +1,83 @@
+#include "context.hpp"
+
+#include <cstring>
+
+namespace dk {
+
+const char *kernel_slot_name(int slot) {
+    static const char *names[K_SLOT_COUNT] = {
+        "k_sym_hist",     "k_pack_keys",   "k_radix_hist",   "k_radix_scan",  "k_radix_scatter", "k_rerank_reduce", "k_rerank_scan",
+        "k_rerank_apply", "k_build_keys",  "k_bwt_gather",   "k_dc_summary",  "k_dc_scan",       "k_dc_main",       "k_dc_sweep",
+        "k_ibwt_hist",    "k_ibwt_lf",     "k_ibwt_walk",    "k_ibwt_rank",   "k_ibwt_emit",     "misc"};
+    return (slot >= 0 && slot < K_SLOT_COUNT) ? names[slot] : nullptr;
+}
+
+}  // namespace dk
+
+int dk_ctx::fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+}
+
+void *dk_ctx::ws_alloc_bytes(size_t bytes) {
+    const size_t aligned = (bytes + 255) & ~static_cast<size_t>(255);
+    if (ws_used + aligned > ws_size) {
+        fail(DK_E_NOMEM, "device workspace exhausted: need %zu more bytes, %zu of %zu in use (block larger than dk_capacity?)",
+             aligned, ws_used, ws_size);
+        return nullptr;
+    }
+    void *p = ws + ws_used;
+    ws_used += aligned;
+    if (ws_used > ws_peak) ws_peak = ws_used;
+    return p;
+}
+
+void dk_ctx::prof_begin(int slot, double bytes) {
+    if (ev_next + 2 > ev_pool.size()) {
+        for (int i = 0; i < 64; ++i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            ev_pool.push_back(e);
+        }
+    }
+    Pending p{slot, ev_pool[ev_next], ev_pool[ev_next + 1], bytes};
+    ev_next += 2;
+    (void)hipEventRecord(p.a, stream);
+    ev_pending.push_back(p);
+}
+
+void dk_ctx::prof_end() {
+    if (ev_pending.empty()) return;
+    (void)hipEventRecord(ev_pending.back().b, stream);
+}
+
+void dk_ctx::prof_collect() {
+    if (ev_pending.empty()) return;
+    (void)hipStreamSynchronize(stream);
+    for (const Pending &p : ev_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            stats.kernel_ms[p.slot] += ms;
+            stats.kernel_bytes[p.slot] += p.bytes;
+            stats.kernel_launches[p.slot] += 1;
+        }
+    }
+    ev_pending.clear();
+    ev_next = 0;
+}
+
+int dk_ctx::ensure_stage(size_t bytes) {
+    if (bytes <= h_stage_size) return DK_OK;
+    if (h_stage) (void)hipHostFree(h_stage);
+    h_stage = nullptr;
+    h_stage_size = 0;
+    if (hipHostMalloc(reinterpret_cast<void **>(&h_stage), bytes, hipHostMallocDefault) != hipSuccess)
+        return fail(DK_E_NOMEM, "pinned staging allocation of %zu bytes failed", bytes);
+    h_stage_size = bytes;
+    return DK_OK;
+}

@@ -1,0 +1,130 @@
+// dk_ctx: one (host thread, GPU) pair.  Owns the HIP stream, the device workspace and the statistics.
+// Mirrors the ownership of saca::Constructor (src/saca.rs:344-384: one storage buffer sized for max_n and reused
+// across calls) plus block::dc::{Encoder,Decoder} (src/block/dc.rs:21-26,96-102).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/dark_amd.h"
+
+namespace dk {
+
+// kernel slots for dk_stats (index into kernel_ms / kernel_bytes / kernel_launches)
+enum KernelSlot : int {
+    K_SYM_HIST = 0,
+    K_PACK_KEYS,
+    K_RADIX_HIST,
+    K_RADIX_SCAN,
+    K_RADIX_SCATTER,
+    K_RERANK_REDUCE,
+    K_RERANK_SCAN,
+    K_RERANK_APPLY,
+    K_BUILD_KEYS,
+    K_BWT_GATHER,
+    K_DC_SUMMARY,
+    K_DC_SCAN,
+    K_DC_MAIN,
+    K_DC_SWEEP,
+    K_IBWT_HIST,
+    K_IBWT_LF,
+    K_IBWT_WALK,
+    K_IBWT_RANK,
+    K_IBWT_EMIT,
+    K_MISC,
+    K_SLOT_COUNT
+};
+static_assert(K_SLOT_COUNT <= DK_NUM_KERNEL_SLOTS, "grow DK_NUM_KERNEL_SLOTS");
+const char *kernel_slot_name(int slot);
+
+struct Timer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+}  // namespace dk
+
+struct dk_ctx {
+    int device = -1;
+    size_t max_n = 0;
+    hipStream_t stream = nullptr;
+    // device workspace: one allocation, bump-allocated per API call (all stages of a call run in sequence)
+    char *ws = nullptr;
+    size_t ws_size = 0, ws_used = 0, ws_peak = 0;
+    // small pinned host mailbox for counters read back between rounds
+    uint32_t *h_mail = nullptr;   // 1024 words, hipHostMalloc
+    uint32_t *d_mail = nullptr;   // 1024 words on the device
+    // pinned staging for D2H of the DC stream
+    char *h_stage = nullptr;
+    size_t h_stage_size = 0;
+    std::string err;
+    dk_stats stats{};
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    struct Pending { int slot; hipEvent_t a, b; double bytes; };
+    std::vector<Pending> ev_pending;
+    size_t ev_next = 0;
+
+    int fail(int code, const char *fmt, ...) __attribute__((format(printf, 3, 4)));
+
+    void ws_reset() { ws_used = 0; }
+    // 256-byte aligned bump allocation; returns nullptr (and records the error) when the workspace is exhausted
+    void *ws_alloc_bytes(size_t bytes);
+    template <class T> T *ws_alloc(size_t count) { return static_cast<T *>(ws_alloc_bytes(count * sizeof(T))); }
+    size_t ws_mark() const { return ws_used; }
+    void ws_release(size_t mark) { ws_used = mark; }
+
+    // profiling: bracket a kernel launch with events on the context's stream
+    void prof_begin(int slot, double bytes);
+    void prof_end();
+    void prof_collect();  // after a stream sync: fold finished event pairs into stats
+    int ensure_stage(size_t bytes);
+};
+
+namespace dk {
+
+#define DK_HIP(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) return (ctx)->fail(DK_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+#define DK_TRY(expr)            \
+    do {                        \
+        int rc_ = (expr);       \
+        if (rc_ != DK_OK) return rc_; \
+    } while (0)
+
+// RAII kernel bracket: DK_LAUNCH(ctx, slot, bytes) { kernel<<<...>>>(...); }
+struct LaunchScope {
+    dk_ctx *c;
+    LaunchScope(dk_ctx *ctx, int slot, double bytes) : c(ctx) { if (c->profiling) c->prof_begin(slot, bytes); }
+    ~LaunchScope() { if (c->profiling) c->prof_end(); }
+};
+
+inline size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
+inline unsigned ceil_log2_u64(uint64_t v) {  // smallest b with (1 << b) >= v
+    unsigned b = 0;
+    while (b < 64 && (1ull << b) < v) ++b;
+    return b;
+}
+
+// ---- device stages (each enqueues on ctx->stream; the ones returning host values synchronise) -------------------
+// radix_sort.hip
+int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
+               int begin_bit, int end_bit);
+// suffix_array.hip: d_sa_out may alias nothing in the workspace; d_text is caller or ctx owned
+int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_sa_out);
+// bwt.hip
+int bwt_gather_device(dk_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, size_t n, uint8_t *d_bwt, uint32_t *origin);
+int bwt_inverse_device(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t origin, uint8_t *d_out);
+// dc.hip: d_run_end may be null
+int dc_encode_device(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t init_host[256], uint32_t *d_dist, uint8_t *d_sym,
+                     uint8_t *d_rank, uint32_t *d_run_end, size_t *m);
+
+}  // namespace dk

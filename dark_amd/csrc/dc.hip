@@ -1,0 +1,302 @@
+// Distance coding of the BWT on the GPU.  Replaces compress::bwt::mtf::MTF + compress::bwt::dc::encode + EncodeIterator as
+// driven by src/block/dc.rs:51-52,82-85 (in-repo analogue etc/dark-c/src/ptax.cpp:61-111).
+//
+// What the serial reference computes, restated without the move-to-front list: the BWT is a sequence of runs.  For a
+// run of symbol s starting at i whose previous occurrence of s ended at b, the MTF rank of s at i is the number of
+// DISTINCT symbols seen in (b, i) = #{c : last_c(i) > b}, and the distance stored for position b is i - b - rank - 1.
+// First occurrences go to init[s] = i.  After the last position every symbol's final run end gets
+// n - b - rank - 1 with rank = #{c : last_c(n) > b} (its place in the final MTF list).  One entry per run, in position
+// order, is exactly what EncodeIterator yields; Context.last_rank of the entry for run r is the rank found at r's start.
+//
+//   k_dc_summary   one wave per tile of 4096 positions: last position (+ run index) of every symbol inside the tile,
+//                  number of run starts in the tile
+//   k_dc_runscan   exclusive sum of the run counts                     (run index of every tile's first new run)
+//   k_dc_carry_*   256-way "last non-empty" exclusive scan over tiles  (last occurrence before each tile, per symbol)
+//   k_dc_main      one wave per tile walks its runs in order; the 256-entry last-occurrence table lives in registers
+//                  (4 per lane), a rank is 4 compare+ballot+popcount, results go straight to the compact arrays
+//   k_dc_sweep     the final 256 distances
+// Algorithmic bytes: 3 n (three reads of L) + 6 m (dist, sym, rank per run) + 2 * 2 KiB per tile of tables.
+#include "context.hpp"
+#include "device_util.hpp"
+
+namespace dk {
+namespace {
+
+constexpr int DC_BLOCK = 256;
+constexpr int DC_WAVES = DC_BLOCK / 64;
+constexpr int DC_TILE = 4096;        // positions per wave
+constexpr int DC_PAD = 16;           // tile bytes start at offset 16 in LDS; byte 15 holds L[base-1]
+constexpr int DC_MAX_CHUNKS = 256;
+
+// Stage L[base-1 .. base+DC_TILE] of one tile into wave-private LDS: s[DC_PAD + j] = L[base + j].
+__device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ L, size_t n, size_t base, uint8_t *s, int lane) {
+    const bool aligned = (reinterpret_cast<uintptr_t>(L) & 15) == 0;
+    for (int j = lane * 16; j < DC_TILE; j += 64 * 16) {
+        const size_t p = base + j;
+        if (aligned && p + 16 <= n) {
+            *reinterpret_cast<uint4 *>(s + DC_PAD + j) = *reinterpret_cast<const uint4 *>(L + p);
+        } else {
+            for (int b = 0; b < 16; ++b) s[DC_PAD + j + b] = (p + b < n) ? L[p + b] : 0;
+        }
+    }
+    if (lane == 0) {
+        s[DC_PAD - 1] = base > 0 ? L[base - 1] : 0;
+        s[DC_PAD + DC_TILE] = (base + DC_TILE < n) ? L[base + DC_TILE] : 0;
+    }
+}
+
+__global__ __launch_bounds__(DC_BLOCK) void k_dc_summary(const uint8_t *__restrict__ L, size_t n, size_t ntiles,
+                                                          uint32_t *__restrict__ tile_last, uint32_t *__restrict__ tile_lrun,
+                                                          uint32_t *__restrict__ tile_runs) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[DC_WAVES][DC_PAD + DC_TILE + 16];
+    __shared__ uint32_t s_last[DC_WAVES][256];
+    __shared__ uint32_t s_lrun[DC_WAVES][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t tile = static_cast<size_t>(blockIdx.x) * DC_WAVES + wave;
+    if (tile >= ntiles) return;  // whole wave leaves together; no workgroup barrier below
+    const size_t base = tile * DC_TILE;
+    uint8_t *s = s_tile[wave];
+    for (int k = 0; k < 4; ++k) { s_last[wave][k * 64 + lane] = 0; s_lrun[wave][k * 64 + lane] = 0; }
+    stage_tile(L, n, base, s, lane);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint32_t runs = 0;
+    const uint64_t le = lanemask_lt(lane) | (1ull << lane);
+    for (int chunk = 0; chunk < DC_TILE / 64; ++chunk) {
+        const int j = chunk * 64 + lane;
+        const size_t p = base + j;
+        const bool valid = p < n;
+        const uint32_t c = s[DC_PAD + j];
+        const bool start = valid && (p == 0 || c != s[DC_PAD + j - 1]);
+        const uint64_t m = __ballot(start);
+        const uint32_t incl = runs + static_cast<uint32_t>(__popcll(m & le));
+        // only the last position of a run inside the tile can be the tile's last occurrence of its symbol
+        const bool is_end = valid && (p + 1 >= n || j == DC_TILE - 1 || s[DC_PAD + j + 1] != c);
+        if (is_end) {
+            atomicMax(&s_last[wave][c], static_cast<uint32_t>(p + 1));
+            atomicMax(&s_lrun[wave][c], incl);
+        }
+        runs += static_cast<uint32_t>(__popcll(m));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < 4; ++k) {
+        tile_last[tile * 256 + k * 64 + lane] = s_last[wave][k * 64 + lane];
+        tile_lrun[tile * 256 + k * 64 + lane] = s_lrun[wave][k * 64 + lane];
+    }
+    if (lane == 0) tile_runs[tile] = runs;
+}
+
+// one workgroup: exclusive sum over tiles of the run counts; total -> mail[0]
+__global__ __launch_bounds__(1024) void k_dc_runscan(uint32_t *__restrict__ tile_runs, size_t ntiles, uint32_t *__restrict__ mail) {
+    __shared__ uint32_t s_tmp[16 + 1];
+    const size_t per = (ntiles + 1023) / 1024;
+    const size_t b0 = static_cast<size_t>(threadIdx.x) * per;
+    const size_t b1 = b0 + per < ntiles ? b0 + per : ntiles;
+    uint32_t sum = 0;
+    for (size_t b = b0; b < b1; ++b) sum += tile_runs[b];
+    uint32_t total;
+    uint32_t run = block_excl_sum<16>(sum, s_tmp, &total);
+    for (size_t b = b0; b < b1; ++b) {
+        const uint32_t v = tile_runs[b];
+        tile_runs[b] = run;
+        run += v;
+    }
+    if (threadIdx.x == 0) mail[0] = total;
+}
+
+// carry scan, phase A: last non-empty entry of every symbol within a chunk of tiles.  tile_lrun is turned into a global
+// run index + 1 on the way (tile_run_base + local).
+__global__ __launch_bounds__(256) void k_dc_carry_a(const uint32_t *__restrict__ tile_last, uint32_t *__restrict__ tile_lrun,
+                                                     const uint32_t *__restrict__ tile_run_base, size_t ntiles, size_t tpc,
+                                                     uint32_t *__restrict__ chunk_last, uint32_t *__restrict__ chunk_lrun) {
+    const size_t g = blockIdx.x, t0 = g * tpc, t1 = t0 + tpc < ntiles ? t0 + tpc : ntiles;
+    const int c = threadIdx.x;
+    uint32_t lp = 0, lr = 0;
+    for (size_t t = t0; t < t1; ++t) {
+        const uint32_t p = tile_last[t * 256 + c];
+        if (p) {
+            const uint32_t r = tile_run_base[t] + tile_lrun[t * 256 + c];
+            tile_lrun[t * 256 + c] = r;
+            lp = p;
+            lr = r;
+        }
+    }
+    chunk_last[g * 256 + c] = lp;
+    chunk_lrun[g * 256 + c] = lr;
+}
+// phase B (one workgroup): exclusive over chunks
+__global__ __launch_bounds__(256) void k_dc_carry_b(uint32_t *__restrict__ chunk_last, uint32_t *__restrict__ chunk_lrun, size_t nchunks) {
+    const int c = threadIdx.x;
+    uint32_t lp = 0, lr = 0;
+    for (size_t g = 0; g < nchunks; ++g) {
+        const uint32_t p = chunk_last[g * 256 + c], r = chunk_lrun[g * 256 + c];
+        chunk_last[g * 256 + c] = lp;
+        chunk_lrun[g * 256 + c] = lr;
+        if (p) { lp = p; lr = r; }
+    }
+}
+// phase C: tables become exclusive carries (last occurrence strictly before the tile)
+__global__ __launch_bounds__(256) void k_dc_carry_c(uint32_t *__restrict__ tile_last, uint32_t *__restrict__ tile_lrun, size_t ntiles,
+                                                     size_t tpc, const uint32_t *__restrict__ chunk_last,
+                                                     const uint32_t *__restrict__ chunk_lrun) {
+    const size_t g = blockIdx.x, t0 = g * tpc, t1 = t0 + tpc < ntiles ? t0 + tpc : ntiles;
+    const int c = threadIdx.x;
+    uint32_t lp = chunk_last[g * 256 + c], lr = chunk_lrun[g * 256 + c];
+    for (size_t t = t0; t < t1; ++t) {
+        const uint32_t p = tile_last[t * 256 + c], r = tile_lrun[t * 256 + c];
+        tile_last[t * 256 + c] = lp;
+        tile_lrun[t * 256 + c] = lr;
+        if (p) { lp = p; lr = r; }
+    }
+}
+
+__device__ __forceinline__ uint32_t sel4(const uint32_t v[4], uint32_t k) {
+    return k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3]));
+}
+
+__global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict__ L, size_t n, size_t ntiles,
+                                                       const uint32_t *__restrict__ carry_last, const uint32_t *__restrict__ carry_lrun,
+                                                       const uint32_t *__restrict__ tile_run_base, uint32_t *__restrict__ dist,
+                                                       uint8_t *__restrict__ sym, uint8_t *__restrict__ rank, uint32_t *__restrict__ run_end,
+                                                       uint32_t *__restrict__ init, uint32_t *__restrict__ final_last,
+                                                       uint32_t *__restrict__ final_lrun) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[DC_WAVES][DC_PAD + DC_TILE + 16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t tile = static_cast<size_t>(blockIdx.x) * DC_WAVES + wave;
+    if (tile >= ntiles) return;
+    const size_t base = tile * DC_TILE;
+    uint8_t *s = s_tile[wave];
+    stage_tile(L, n, base, s, lane);
+    // lp[k] / lr[k]: last position + 1 and run index + 1 of symbol k*64 + lane (0 = not seen yet)
+    uint32_t lp[4], lr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        lp[k] = carry_last[tile * 256 + k * 64 + lane];
+        lr[k] = carry_lrun[tile * 256 + k * 64 + lane];
+    }
+    uint32_t r = tile_run_base[tile];  // index of the next run to start
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int chunk = 0; chunk < DC_TILE / 64; ++chunk) {
+        const int j = chunk * 64 + lane;
+        const size_t p = base + j;
+        const uint32_t c = s[DC_PAD + j];
+        const uint32_t pc = s[DC_PAD + j - 1];
+        const bool start = p < n && (p == 0 || c != pc);
+        uint64_t m = __ballot(start);
+        while (m) {
+            const int bit = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t i = static_cast<uint32_t>(base + chunk * 64 + bit);
+            const uint32_t cs = __builtin_amdgcn_readlane(c, bit);
+            const uint32_t ps = __builtin_amdgcn_readlane(pc, bit);
+            if (i > 0) {  // the run of `ps` ended at i-1; it is run r-1
+                const uint32_t kk = ps >> 6, ll = ps & 63;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (static_cast<uint32_t>(k) == kk && static_cast<uint32_t>(lane) == ll) { lp[k] = i; lr[k] = r; }
+                if (run_end && lane == 0) run_end[r - 1] = i - 1;
+            }
+            const uint32_t b1 = __builtin_amdgcn_readlane(sel4(lp, cs >> 6), cs & 63);
+            const uint32_t rb1 = __builtin_amdgcn_readlane(sel4(lr, cs >> 6), cs & 63);
+            uint32_t cnt = 0;
+            if (b1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cnt += static_cast<uint32_t>(__popcll(__ballot(lp[k] > b1)));
+            }
+            if (lane == 0) {
+                if (b1) dist[rb1 - 1] = i - b1 - cnt;  // = i - b - rank - 1 with b = b1 - 1
+                else init[cs] = i;
+                sym[r] = static_cast<uint8_t>(cs);
+                if (rank) rank[r] = static_cast<uint8_t>(cnt);
+            }
+            ++r;
+        }
+    }
+    if (tile == ntiles - 1) {  // close the last run of the block and publish the final table for the sweep
+        const uint32_t ps = L[n - 1];
+        const uint32_t kk = ps >> 6, ll = ps & 63;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (static_cast<uint32_t>(k) == kk && static_cast<uint32_t>(lane) == ll) { lp[k] = static_cast<uint32_t>(n); lr[k] = r; }
+        if (run_end && lane == 0) run_end[r - 1] = static_cast<uint32_t>(n - 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            final_last[k * 64 + lane] = lp[k];
+            final_lrun[k * 64 + lane] = lr[k];
+        }
+    }
+}
+
+// final sweep (one workgroup): every present symbol's last run end gets n - b - rank - 1, rank = place in the final MTF order
+__global__ __launch_bounds__(256) void k_dc_sweep(const uint32_t *__restrict__ final_last, const uint32_t *__restrict__ final_lrun,
+                                                   uint32_t n, uint32_t *__restrict__ dist) {
+    __shared__ uint32_t s_last[256];
+    const int c = threadIdx.x;
+    const uint32_t fp = final_last[c];
+    s_last[c] = fp;
+    __syncthreads();
+    if (!fp) return;
+    uint32_t cnt = 0;
+    for (int o = 0; o < 256; ++o) cnt += s_last[o] > fp;
+    dist[final_lrun[c] - 1] = n - fp - cnt;
+}
+
+__global__ __launch_bounds__(256) void k_fill_u32(uint32_t *p, size_t count, uint32_t v) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < count) p[i] = v;
+}
+
+}  // namespace
+
+int dc_encode_device(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t init_host[256], uint32_t *d_dist, uint8_t *d_sym,
+                     uint8_t *d_rank, uint32_t *d_run_end, size_t *m) {
+    if (n == 0 || n > 0xFFFFFFF0ull) return ctx->fail(DK_E_ARG, "dc_encode: n out of range");
+    hipStream_t st = ctx->stream;
+    const size_t mark = ctx->ws_mark();
+    const size_t ntiles = div_up(n, DC_TILE);
+    const size_t nblocks = div_up(ntiles, DC_WAVES);
+    const size_t tpc = div_up(ntiles, DC_MAX_CHUNKS);
+    const size_t nchunks = div_up(ntiles, tpc);
+    uint32_t *tile_last = ctx->ws_alloc<uint32_t>(ntiles * 256);
+    uint32_t *tile_lrun = ctx->ws_alloc<uint32_t>(ntiles * 256);
+    uint32_t *tile_runs = ctx->ws_alloc<uint32_t>(ntiles);
+    uint32_t *chunk_last = ctx->ws_alloc<uint32_t>(nchunks * 256);
+    uint32_t *chunk_lrun = ctx->ws_alloc<uint32_t>(nchunks * 256);
+    uint32_t *d_init = ctx->ws_alloc<uint32_t>(256);
+    uint32_t *d_final = ctx->ws_alloc<uint32_t>(512);
+    if (!tile_last || !tile_lrun || !tile_runs || !chunk_last || !chunk_lrun || !d_init || !d_final) return DK_E_NOMEM;
+    {
+        LaunchScope ls(ctx, K_DC_SUMMARY, 1.0 * n + 2048.0 * ntiles);
+        k_dc_summary<<<dim3(nblocks), dim3(DC_BLOCK), 0, st>>>(d_bwt, n, ntiles, tile_last, tile_lrun, tile_runs);
+    }
+    {
+        LaunchScope ls(ctx, K_DC_SCAN, 3.0 * 2048.0 * ntiles);
+        k_dc_runscan<<<dim3(1), dim3(1024), 0, st>>>(tile_runs, ntiles, ctx->d_mail);
+        k_dc_carry_a<<<dim3(nchunks), dim3(256), 0, st>>>(tile_last, tile_lrun, tile_runs, ntiles, tpc, chunk_last, chunk_lrun);
+        k_dc_carry_b<<<dim3(1), dim3(256), 0, st>>>(chunk_last, chunk_lrun, nchunks);
+        k_dc_carry_c<<<dim3(nchunks), dim3(256), 0, st>>>(tile_last, tile_lrun, ntiles, tpc, chunk_last, chunk_lrun);
+        k_fill_u32<<<dim3(1), dim3(256), 0, st>>>(d_init, 256, static_cast<uint32_t>(n));
+    }
+    {
+        LaunchScope ls(ctx, K_DC_MAIN, 1.0 * n + 2048.0 * ntiles);
+        k_dc_main<<<dim3(nblocks), dim3(DC_BLOCK), 0, st>>>(d_bwt, n, ntiles, tile_last, tile_lrun, tile_runs, d_dist, d_sym, d_rank,
+                                                            d_run_end, d_init, d_final, d_final + 256);
+    }
+    {
+        LaunchScope ls(ctx, K_DC_SWEEP, 2048.0);
+        k_dc_sweep<<<dim3(1), dim3(256), 0, st>>>(d_final, d_final + 256, static_cast<uint32_t>(n), d_dist);
+    }
+    DK_HIP(ctx, hipGetLastError());
+    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 16, d_init, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    DK_HIP(ctx, hipStreamSynchronize(st));
+    *m = ctx->h_mail[0];
+    for (int s = 0; s < 256; ++s) init_host[s] = ctx->h_mail[16 + s];
+    ctx->stats.dc_runs = *m;
+    ctx->ws_release(mark);
+    return DK_OK;
+}
+
+}  // namespace dk

@@ -1,0 +1,557 @@
+// Host entropy stage: see entropy.hpp for what each piece replaces in the reference.
+#include "entropy.hpp"
+
+#include <algorithm>
+#include <vector>
+
+namespace dk {
+
+// ------------------------------------------------------------------------------------------------------------------
+// dark model (src/model/dark.rs)
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr unsigned kMaxLogCode = 8;      // dark.rs:46
+constexpr unsigned kMaxLogContext = 11;  // dark.rs:47
+constexpr unsigned kMaxBitContext = 3;   // dark.rs:49
+constexpr int kAdaptPowers[9] = {6, 5, 4, 3, 2, 1, 4, 6, 4};  // dark.rs:50
+constexpr unsigned kLogGlobalRate = 12, kLogSymbolRate = 5;   // dark.rs:141-142
+constexpr uint32_t kLogAdd = 5;                               // dark.rs:143
+inline unsigned token_of(unsigned log) { return log < 2 ? 0u : (log < 8 ? 1u : 2u); }  // dark.rs:214
+}  // namespace
+
+void DarkModel::reset() {  // dark.rs:121-146,160-178
+    for (auto &row : log_global_) for (auto &t : row) t.flat();
+    for (auto &row : log_bits_) for (auto &b : row) b.flat();
+    for (auto &row : mantissa_) for (auto &b : row) b.flat();
+    for (auto &c : sym_) {
+        c.avg_dist = 1000;
+        c.log_freq.flat();
+        for (auto &b : c.extra) b.flat();
+    }
+    last_token_ = 1;
+}
+
+inline void DarkModel::adapt(PerSymbol &c, uint32_t dist, int log_diff) {  // dark.rs:94-101
+    const int64_t a = log_diff < -6 ? 7 : (log_diff >= 3 ? 3 : kAdaptPowers[6 + log_diff]);
+    c.avg_dist += (a * (static_cast<int64_t>(dist) - c.avg_dist)) >> 3;  // floor, like isize >> 3
+}
+
+bool DarkModel::encode(uint32_t dist, uint8_t symbol, Encoder &e) {  // dark.rs:180-232
+    if (dist >= 0x7FFFFFFFu) return false;  // log would reach 32: freq_mantissa has 32 rows
+    const uint32_t v = dist + 1;
+    const unsigned log = bit_length(v);
+    PerSymbol &c = sym_[symbol];
+    const unsigned avg_log = std::min(kMaxLogContext, bit_length(static_cast<uint32_t>(c.avg_dist)));
+    {
+        FreqTable<8> &g = log_global_[avg_log][last_token_];
+        const size_t code = std::min(log, kMaxLogCode) - 1;
+        if (!encode_mix12(e, c.log_freq, g, code)) return false;
+        c.log_freq.bump(code, kLogSymbolRate, kLogAdd);
+        g.bump(code, kLogGlobalRate, kLogAdd);
+    }
+    if (log >= kMaxLogCode) {  // unary extension, one mixed binary decision per extra bit of exponent
+        BinFreq *gb = log_bits_[avg_log == kMaxLogContext ? 1 : 0];
+        for (unsigned i = 0; i + kMaxLogCode < log; ++i) {
+            if (!encode_bit_p(e, (c.extra[i].zero + gb[i].zero) >> 1, true)) return false;
+            c.extra[i].learn<3>(true);
+            gb[i].learn<2>(true);
+        }
+        const unsigned i = log - kMaxLogCode;
+        if (!encode_bit_p(e, (c.extra[i].zero + gb[i].zero) >> 1, false)) return false;
+        c.extra[i].learn<3>(false);
+        gb[i].learn<2>(false);
+    }
+    last_token_ = token_of(log);
+    BinFreq *mc = mantissa_[log];
+    for (unsigned i = 1; i < log; ++i) {  // mantissa below the leading one, MSB first
+        const bool bit = (v >> (log - i - 1)) & 1u;
+        if (i > kMaxBitContext) {
+            if (!encode_bit_p(e, mc[kMaxBitContext].zero, bit)) return false;  // 4th model never adapts (dark.rs:221)
+        } else {
+            if (!encode_bit_p(e, mc[i - 1].zero, bit)) return false;
+            mc[i - 1].learn<8>(bit);
+        }
+    }
+    adapt(c, dist, static_cast<int>(log) - static_cast<int>(avg_log));
+    return e.error() == 0;
+}
+
+bool DarkModel::decode(uint8_t symbol, Decoder &d, uint32_t &dist) {  // dark.rs:234-287
+    PerSymbol &c = sym_[symbol];
+    const unsigned avg_log = std::min(kMaxLogContext, bit_length(static_cast<uint32_t>(c.avg_dist)));
+    unsigned log;
+    {
+        FreqTable<8> &g = log_global_[avg_log][last_token_];
+        size_t code;
+        if (!decode_mix12(d, c.log_freq, g, code)) return false;
+        c.log_freq.bump(code, kLogSymbolRate, kLogAdd);
+        g.bump(code, kLogGlobalRate, kLogAdd);
+        log = static_cast<unsigned>(code) + 1;
+    }
+    if (log >= kMaxLogCode) {
+        BinFreq *gb = log_bits_[avg_log == kMaxLogContext ? 1 : 0];
+        unsigned count = 0;
+        for (;;) {
+            if (count >= 32) return d.fail(DK_E_STREAM);
+            bool bit;
+            if (!decode_bit_p(d, (c.extra[count].zero + gb[count].zero) >> 1, bit)) return false;
+            c.extra[count].learn<3>(bit);
+            gb[count].learn<2>(bit);
+            if (!bit) break;
+            ++count;
+        }
+        log += count;
+    }
+    if (log >= 32) return d.fail(DK_E_STREAM);
+    last_token_ = token_of(log);
+    BinFreq *mc = mantissa_[log];
+    uint32_t v = 1;
+    for (unsigned i = 1; i < log; ++i) {
+        bool bit;
+        if (i > kMaxBitContext) {
+            if (!decode_bit_p(d, mc[kMaxBitContext].zero, bit)) return false;
+        } else {
+            if (!decode_bit_p(d, mc[i - 1].zero, bit)) return false;
+            mc[i - 1].learn<8>(bit);
+        }
+        v = (v << 1) + (bit ? 1u : 0u);
+    }
+    dist = v - 1;
+    adapt(c, dist, static_cast<int>(log) - static_cast<int>(avg_log));
+    return d.error() == 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// exp model (src/model/exp.rs) on apm::Bit (12-bit probability of zero; update(value, 5, 0))
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr uint32_t kFixedBase = 8, kFixedMask = (1u << kFixedBase) - 1;
+inline void apm_learn(uint16_t &p, bool one) {  // apm::Bit::update(value, rate = 5, bias = 0)
+    if (one) p = static_cast<uint16_t>(p - (p >> 5)); else p = static_cast<uint16_t>(p + ((4096 - p) >> 5));
+}
+}  // namespace
+
+void ExpModel::reset() {  // exp.rs:47-56
+    for (auto &a : avg_log_) a = 1u << kFixedBase;
+    for (auto &row : prob_) for (auto &p : row) p = 2048;
+}
+uint32_t ExpModel::log_fixed(uint32_t d) {  // exp.rs:34-43 with its integer quirks (8/3 == 2, 8>>12 == 0)
+    if (d <= 2) return d << kFixedBase;
+    if (d <= 4) return (3u << kFixedBase) + (d & 1) * (kFixedBase >> 1);
+    if (d <= 7) return (4u << kFixedBase) + ((d - 5) % 3) * (kFixedBase / 3);
+    if (d <= 12) return (5u << kFixedBase) + (d & 3) * (kFixedBase >> 2);
+    return (6u << kFixedBase) + (d - 12) * (kFixedBase >> 12);
+}
+bool ExpModel::encode(uint32_t dist, uint8_t symbol, Encoder &e) {  // exp.rs:58-78
+    const uint32_t log = avg_log_[symbol];
+    const uint32_t w2 = log & kFixedMask, w1 = kFixedMask + 1 - w2;
+    uint16_t *m1 = prob_[log >> kFixedBase], *m2 = prob_[(log >> kFixedBase) + 1];
+    for (int i = 23; i >= 0; --i) {  // only 24 bits are coded: higher bits of dist are dropped (exp.rs:22,67)
+        const bool bit = (dist >> i) & 1u;
+        const uint32_t flat = (w1 * m1[i] + w2 * m2[i]) >> kFixedBase;
+        if (!encode_bit_p(e, flat, bit)) return false;
+        apm_learn(m1[i], bit);
+        apm_learn(m2[i], bit);
+    }
+    avg_log_[symbol] = (3 * log + log_fixed(dist)) >> 2;
+    return true;
+}
+bool ExpModel::decode(uint8_t symbol, Decoder &d, uint32_t &dist) {  // exp.rs:80-101
+    const uint32_t log = avg_log_[symbol];
+    const uint32_t w2 = log & kFixedMask, w1 = kFixedMask + 1 - w2;
+    uint16_t *m1 = prob_[log >> kFixedBase], *m2 = prob_[(log >> kFixedBase) + 1];
+    uint32_t v = 0;
+    for (int i = 23; i >= 0; --i) {
+        const uint32_t flat = (w1 * m1[i] + w2 * m2[i]) >> kFixedBase;
+        bool bit;
+        if (!decode_bit_p(d, flat, bit)) return false;
+        apm_learn(m1[i], bit);
+        apm_learn(m2[i], bit);
+        v += v + (bit ? 1u : 0u);
+    }
+    avg_log_[symbol] = (3 * log + log_fixed(v)) >> 2;
+    dist = v;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// ybs model (src/model/ybs.rs)
+// ------------------------------------------------------------------------------------------------------------------
+void YbsModel::reset() {  // ybs.rs:54-65,75-87
+    for (auto &t : low_) t.flat();
+    high_.flat();
+    for (auto &b : rest_) b.flat();
+    for (auto &c : sym_) c.avg_log = c.last_diff = 0;
+}
+void YbsModel::track(PerSymbol &c, uint32_t log) {  // ybs.rs:33-38
+    const uint32_t a = c.last_diff > 3 ? 2 : 1;
+    c.last_diff = log > c.avg_log ? log - c.avg_log : c.avg_log - log;
+    c.avg_log = (a * log + c.avg_log) / (a + 1);
+}
+bool YbsModel::encode(uint32_t dist, uint8_t symbol, Encoder &e) {  // ybs.rs:89-127
+    constexpr uint32_t kMaxLow = 12;
+    const uint32_t group = dist < 4 ? dist : bit_length(dist) + 1;
+    PerSymbol &c = sym_[symbol];
+    FreqTable<14> &t = low_[std::min(c.avg_log, kMaxLow)];
+    const uint32_t coded = std::min(group, kMaxLow);
+    if (!t.encode(e, coded)) return false;
+    t.bump(coded, 10, 1);
+    track(c, coded);
+    if (group < 4) return true;
+    if (group >= kMaxLow) {
+        const uint32_t add = group - kMaxLow;
+        if (add >= 19) return false;  // table_high has 32-13 entries: the reference would index out of bounds
+        if (!high_.encode(e, add)) return false;
+        high_.bump(add, 10, 1);
+    }
+    const uint32_t log = group - 1;
+    for (uint32_t i = 1; i < log; ++i) {
+        const bool bit = (dist >> (log - i - 1)) & 1u;
+        if (i >= 3) {
+            if (!encode_bit_p(e, rest_[2].zero, bit)) return false;  // un-updated last bin (ybs.rs:119)
+        } else {
+            if (!encode_bit_p(e, rest_[i - 1].zero, bit)) return false;
+            rest_[i - 1].learn<5>(bit);
+        }
+    }
+    return true;
+}
+bool YbsModel::decode(uint8_t symbol, Decoder &d, uint32_t &dist) {  // ybs.rs:129-165
+    constexpr uint32_t kMaxLow = 12;
+    PerSymbol &c = sym_[symbol];
+    FreqTable<14> &t = low_[std::min(c.avg_log, kMaxLow)];
+    size_t coded;
+    if (!t.decode(d, coded)) return false;
+    track(c, static_cast<uint32_t>(coded));
+    t.bump(coded, 10, 1);
+    if (coded < 4) { dist = static_cast<uint32_t>(coded); return true; }
+    uint32_t group = static_cast<uint32_t>(coded);
+    if (coded == kMaxLow) {
+        size_t add;
+        if (!high_.decode(d, add)) return false;
+        high_.bump(add, 10, 1);
+        group = kMaxLow + static_cast<uint32_t>(add);
+    }
+    const uint32_t log = group - 1;
+    uint32_t v = 1;
+    for (uint32_t i = 1; i < log; ++i) {
+        bool bit;
+        if (i >= 3) {
+            if (!decode_bit_p(d, rest_[2].zero, bit)) return false;
+        } else {
+            if (!decode_bit_p(d, rest_[i - 1].zero, bit)) return false;
+            rest_[i - 1].learn<5>(bit);
+        }
+        v = (v << 1) + (bit ? 1u : 0u);
+    }
+    dist = v;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// simple model (src/model/simple.rs)
+// ------------------------------------------------------------------------------------------------------------------
+namespace { constexpr unsigned kSimpleUp[4] = {10, 8, 7, 6}; }  // simple.rs:38
+void SimpleModel::reset() { for (auto &t : freq_) t.flat(); }
+bool SimpleModel::encode(uint32_t dist, uint8_t, Encoder &e) {  // simple.rs:51-64
+    const uint32_t head = std::min<uint32_t>(0xFF, dist);
+    if (!freq_[0].encode(e, head)) return false;
+    freq_[0].bump(head, kSimpleUp[0], 1);
+    if (head == 0xFF) {
+        const uint32_t rest = dist - 0xFF;
+        for (int i = 0; i < 3; ++i) {
+            const uint32_t b = (rest >> (8 * i)) & 0xFF;
+            if (!freq_[i + 1].encode(e, b)) return false;
+            freq_[i + 1].bump(b, kSimpleUp[i + 1], 1);
+        }
+    }
+    return true;
+}
+bool SimpleModel::decode(uint8_t, Decoder &d, uint32_t &dist) {  // simple.rs:66-80
+    size_t head;
+    if (!freq_[0].decode(d, head)) return false;
+    freq_[0].bump(head, kSimpleUp[0], 1);
+    uint32_t v = static_cast<uint32_t>(head);
+    if (head == 0xFF) {
+        for (int i = 0; i < 3; ++i) {
+            size_t b;
+            if (!freq_[i + 1].decode(d, b)) return false;
+            freq_[i + 1].bump(b, kSimpleUp[i + 1], 1);
+            v += static_cast<uint32_t>(b) << (8 * i);
+        }
+    }
+    dist = v;
+    return true;
+}
+
+uint64_t model_max_block(int model_id) {
+    switch (model_id) {
+    case DK_MODEL_DARK: return 0x7FFFFFFEull;         // dist + 1 must have < 32 significant bits
+    case DK_MODEL_EXP: return 1ull << 24;             // 24 coded bits (exp.rs:67)
+    case DK_MODEL_YBS: return 1ull << 29;             // group - 12 < 19 (ybs.rs:59,110-113)
+    case DK_MODEL_SIMPLE: return (1ull << 24) + 254;  // three extra bytes (simple.rs:56-61)
+    case DK_MODEL_RAWDC: return 0xFFFFFFFEull;
+    default: return 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Block stream layout (src/block/dc.rs)
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// src/block/dc.rs:54-90 with any model M
+template <class M>
+int write_stream(M &model, const DcStream &s, Encoder &e) {
+    const size_t n = s.n;
+    auto code = [&](uint32_t v, uint8_t sym) { return model.encode(v, sym, e); };
+    // Init-table RLE: alternating present / absent run lengths over symbols 0..254; every present symbol is followed
+    // by its first position.  The first present-run length is raw, all later lengths are len-1.  Symbol 0xFF is
+    // never visited (all loops stop at 0xFF): blocks containing byte 0xFF encode, but cannot be decoded.
+    bool active = true;
+    size_t i = 0;
+    while (i < 0xFF) {
+        const size_t base = i;
+        if (active) {
+            while (i < 0xFF && s.init[i] < n) ++i;
+            if (!code(static_cast<uint32_t>(base == 0 ? i : i - base - 1), 0)) return DK_E_MODEL;
+            for (size_t c = base; c < i; ++c)
+                if (!code(s.init[c], static_cast<uint8_t>(c))) return DK_E_MODEL;
+            active = false;
+        } else {
+            do { ++i; } while (i < 0xFF && s.init[i] == n);
+            if (!code(static_cast<uint32_t>(i - base - 1), 0)) return DK_E_MODEL;
+            active = true;
+        }
+    }
+    for (size_t k = 0; k < s.m; ++k)  // src/block/dc.rs:82-85
+        if (!code(s.dist[k], s.sym[k])) return e.error() ? e.error() : DK_E_MODEL;
+    if (!code(s.origin, 0)) return e.error() ? e.error() : DK_E_MODEL;  // src/block/dc.rs:88 under CTX_0
+    if (!e.finish()) return e.error();
+    return DK_OK;
+}
+
+// src/model/raw.rs:12-44: every model.encode call becomes one 10-byte little-endian record
+struct RecordSink {
+    uint8_t *out; size_t cap, len = 0; bool full = false;
+    void rec(uint32_t d, uint8_t sym, uint8_t rank, uint32_t limit) {
+        if (len + 10 > cap) { full = true; return; }
+        uint8_t *p = out + len;
+        for (int i = 0; i < 4; ++i) p[i] = static_cast<uint8_t>(d >> (8 * i));
+        p[4] = sym; p[5] = rank;
+        for (int i = 0; i < 4; ++i) p[6 + i] = static_cast<uint8_t>(limit >> (8 * i));
+        len += 10;
+    }
+};
+int write_records(const DcStream &s, uint8_t *out, size_t cap, size_t *out_len) {
+    if (!s.rank || !s.run_end) return DK_E_ARG;
+    RecordSink r{out, cap};
+    const size_t n = s.n;
+    bool active = true;
+    size_t i = 0;
+    while (i < 0xFF) {  // same control flow as write_stream; CTX_0 = {0, 0, 0x101} (src/block/dc.rs:16-18)
+        const size_t base = i;
+        if (active) {
+            while (i < 0xFF && s.init[i] < n) ++i;
+            r.rec(static_cast<uint32_t>(base == 0 ? i : i - base - 1), 0, 0, 0x101);
+            for (size_t c = base; c < i; ++c) r.rec(s.init[c], static_cast<uint8_t>(c), 0, static_cast<uint32_t>(n));
+            active = false;
+        } else {
+            do { ++i; } while (i < 0xFF && s.init[i] == n);
+            r.rec(static_cast<uint32_t>(i - base - 1), 0, 0, 0x101);
+            active = true;
+        }
+    }
+    for (size_t k = 0; k < s.m; ++k) r.rec(s.dist[k], s.sym[k], s.rank[k], static_cast<uint32_t>(n - s.run_end[k]));
+    r.rec(s.origin, 0, 0, 0x101);
+    *out_len = r.len;
+    return r.full ? DK_E_CAPACITY : DK_OK;
+}
+
+// compress::bwt::dc::decode: rebuilds the BWT from first positions + distances while keeping the symbols ordered by
+// their next known position (the decoder's view of the MTF list).  `next_dist(symbol, &d)` supplies distances.
+template <class F>
+int dc_rebuild(uint32_t const init[256], uint8_t *out, size_t n, F &&next_dist, int *single) {
+    uint64_t next[256];
+    uint8_t order[256];
+    size_t alpha = 0;
+    for (int s = 0; s < 256; ++s) {
+        next[s] = init[s];
+        if (init[s] < n) {  // insertion by first position
+            size_t j = alpha++;
+            while (j > 0 && next[order[j - 1]] > next[s]) { order[j] = order[j - 1]; --j; }
+            order[j] = static_cast<uint8_t>(s);
+        }
+    }
+    if (single) *single = alpha <= 1;
+    if (alpha <= 1) {  // "redundant alphabet": filled without reading any distance
+        std::memset(out, alpha ? order[0] : 0, n);
+        return DK_OK;
+    }
+    size_t i = 0;
+    while (i < n) {
+        const uint8_t sym = order[0];
+        const uint64_t stop = next[order[1]];
+        if (stop > n || stop < i) return DK_E_STREAM;
+        std::memset(out + i, sym, stop - i);
+        i = stop;
+        uint32_t d;
+        if (int rc = next_dist(sym, &d)) return rc;
+        const uint64_t future = stop + d;
+        if (future > n) return DK_E_STREAM;
+        size_t r = 1;
+        while (r < alpha && future + r > next[order[r]]) { order[r - 1] = order[r]; ++r; }
+        order[r - 1] = sym;
+        next[sym] = future + r - 1;
+    }
+    for (int s = 0; s < 256; ++s)
+        if (next[s] < n || next[s] >= n + alpha) return DK_E_STREAM;
+    return DK_OK;
+}
+
+// src/block/dc.rs:121-151
+template <class M>
+int read_stream(M &model, Decoder &d, size_t n, uint8_t *bwt_out, uint32_t *origin, int *single) {
+    uint32_t init[256];
+    for (auto &v : init) v = static_cast<uint32_t>(n);
+    bool active = true;
+    size_t i = 0;
+    while (i < 0xFF) {
+        uint32_t v;
+        if (!model.decode(0, d, v)) return DK_E_STREAM;
+        const size_t num = static_cast<size_t>(v) + ((i == 0 && active) ? 0 : 1);
+        if (active) {
+            for (size_t c = i; c < i + num && c < 0x100; ++c) {
+                if (!model.decode(static_cast<uint8_t>(c), d, v)) return DK_E_STREAM;
+                init[c] = v;
+            }
+        }
+        active = !active;
+        i += num;
+    }
+    int rc = dc_rebuild(init, bwt_out, n, [&](uint8_t sym, uint32_t *out) {
+        return model.decode(sym, d, *out) ? DK_OK : DK_E_STREAM;
+    }, single);
+    if (rc) return rc;
+    if (!model.decode(0, d, *origin)) return DK_E_STREAM;
+    if (!d.finish()) return DK_E_STREAM;
+    return DK_OK;
+}
+
+template <class F>
+int with_model(int model_id, F &&f) {
+    switch (model_id) {
+    case DK_MODEL_DARK: { auto m = std::make_unique<DarkModel>(); return f(*m); }
+    case DK_MODEL_EXP: { auto m = std::make_unique<ExpModel>(); return f(*m); }
+    case DK_MODEL_YBS: { auto m = std::make_unique<YbsModel>(); return f(*m); }
+    case DK_MODEL_SIMPLE: { auto m = std::make_unique<SimpleModel>(); return f(*m); }
+    default: return DK_E_MODEL;
+    }
+}
+
+}  // namespace
+
+int encode_block_stream(int model_id, const DcStream &s, uint8_t *out, size_t cap, size_t *out_len) {
+    if (!s.init || (!s.dist && s.m) || (!s.sym && s.m) || !out || !out_len) return DK_E_ARG;
+    if (model_id == DK_MODEL_RAWDC) return write_records(s, out, cap, out_len);
+    if (s.n > model_max_block(model_id)) return DK_E_MODEL;
+    return with_model(model_id, [&](auto &model) {
+        model.reset();  // Encoder::new resets the model (src/block/dc.rs:31)
+        Encoder e(out, cap);
+        int rc = write_stream(model, s, e);
+        *out_len = e.size();
+        return rc;
+    });
+}
+
+int decode_block_stream(int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *bwt_out,
+                        uint32_t *origin, int *single) {
+    if (!in || !bwt_out || !origin || n == 0) return DK_E_ARG;
+    return with_model(model_id, [&](auto &model) {
+        model.reset();  // src/block/dc.rs:108
+        Decoder d(in, in_len);
+        return read_stream(model, d, n, bwt_out, origin, single);
+    });
+}
+
+int dc_decode_array(const uint32_t init[256], const uint32_t *dist, size_t m, uint8_t *bwt_out, size_t n, size_t *consumed) {
+    size_t k = 0;
+    int rc = dc_rebuild(init, bwt_out, n, [&](uint8_t, uint32_t *out) {
+        if (k >= m) return DK_E_STREAM;
+        *out = dist[k++];
+        return DK_OK;
+    }, nullptr);
+    if (consumed) *consumed = k;
+    return rc;
+}
+
+int model_encode_stream(int model_id, const uint32_t *dist, const uint8_t *sym, size_t m, uint8_t *out, size_t cap, size_t *out_len) {
+    return with_model(model_id, [&](auto &model) {
+        model.reset();
+        Encoder e(out, cap);
+        for (size_t k = 0; k < m; ++k)
+            if (!model.encode(dist[k], sym[k], e)) { *out_len = e.size(); return e.error() ? e.error() : DK_E_MODEL; }
+        bool ok = e.finish();
+        *out_len = e.size();
+        return ok ? DK_OK : e.error();
+    });
+}
+
+int model_decode_stream(int model_id, const uint8_t *in, size_t in_len, const uint8_t *sym, size_t m, uint32_t *dist) {
+    return with_model(model_id, [&](auto &model) {
+        model.reset();
+        Decoder d(in, in_len);
+        for (size_t k = 0; k < m; ++k)
+            if (!model.decode(sym[k], d, dist[k])) return DK_E_STREAM;
+        return DK_OK;
+    });
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Bitwise coder of src/entropy/ari.rs (Range) driven as src/entropy/mod.rs does
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct BitRange {
+    uint32_t lo = 0, hi = 0xFFFFFFFFu;
+    inline uint32_t mid(uint16_t p) const {  // ari.rs:21-30: split point for a 12-bit probability of zero
+        const uint32_t f = p + 1u - (p >> 11);
+        const uint32_t diff = hi - lo;
+        return lo + (diff >> 12) * f + (((diff & 0xFFFu) * f) >> 12);
+    }
+    template <class Emit> inline size_t roll(Emit &&emit) {  // ari.rs:32-42
+        size_t k = 0;
+        while (((lo ^ hi) & kTopMask) == 0) { emit(static_cast<uint8_t>(lo >> 24)); ++k; lo <<= 8; hi = (hi << 8) | 0xFF; }
+        return k;
+    }
+};
+}  // namespace
+
+int bitcoder_encode(const uint8_t *bits, const uint16_t *flat, size_t nbits, uint8_t *out, size_t cap, size_t *out_len) {
+    BitRange r;
+    size_t len = 0;
+    for (size_t k = 0; k < nbits; ++k) {
+        const uint32_t m = r.mid(flat[k]);
+        if (bits[k] == 0) r.hi = m; else r.lo = m + 1;  // ari.rs:44-53
+        if (len + 4 > cap) return DK_E_CAPACITY;
+        r.roll([&](uint8_t b) { out[len++] = b; });
+    }
+    if (len + 4 > cap) return DK_E_CAPACITY;
+    for (int i = 0; i < 4; ++i) out[len++] = static_cast<uint8_t>(r.lo >> (24 - 8 * i));  // post_encode ari.rs:67-73
+    *out_len = len;
+    return DK_OK;
+}
+
+int bitcoder_decode(const uint8_t *in, size_t in_len, const uint16_t *flat, size_t nbits, uint8_t *bits) {
+    BitRange r;
+    uint32_t code = 0;
+    size_t pos = 0, pending = 4;  // entropy/mod.rs:52-68
+    for (size_t k = 0; k < nbits; ++k) {
+        while (pending) { if (pos >= in_len) return DK_E_STREAM; code = (code << 8) + in[pos++]; --pending; }
+        const uint32_t m = r.mid(flat[k]);  // ari.rs:55-65
+        if (code <= m) { r.hi = m; bits[k] = 0; } else { r.lo = m + 1; bits[k] = 1; }
+        pending = r.roll([](uint8_t) {});
+    }
+    return DK_OK;
+}
+
+}  // namespace dk

@@ -1,0 +1,299 @@
+// Host entropy stage of the product: adaptive range coder, frequency models, the four distance models and the
+// block stream layout.  Serial by construction (every coded symbol updates the state the next one reads), so it
+// runs on the host, one block per core, fed by the GPU stages.
+//
+// Replaces: compress::entropy::ari::{Encoder,Decoder,table,bin,apm} as used by src/model/*.rs, the models
+// src/model/{dark,exp,ybs,simple,raw}.rs, the stream layout of src/block/dc.rs:53-90,121-151, compress::bwt::dc::decode
+// (src/block/dc.rs:146-150) and the in-repo bitwise coder src/entropy/{mod,ari}.rs.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+
+#include "../../include/dark_amd.h"
+
+namespace dk {
+
+// ------------------------------------------------------------------------------------------------------------------
+// Range coder: 32-bit [low, hi), carry-less, threshold-cut renormalisation, byte output, 4-byte big-endian tail.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kRangeThreshold = 1u << 14;  // ari::RANGE_DEFAULT_THRESHOLD (dark.rs:149, ybs.rs:69, simple.rs:35 use >>2 of it)
+constexpr uint32_t kModelThreshold = kRangeThreshold >> 2;
+constexpr uint32_t kTopMask = 0xFF000000u;
+
+struct RangeState {
+    uint32_t low = 0, hi = 0xFFFFFFFFu;
+    // Narrow to [low + r*from, low + r*to) and renormalise; bytes leaving the top go to `emit`.
+    // Returns the number of bytes shifted out, or -1 when the interval is degenerate.
+    template <class Emit>
+    inline int narrow(uint32_t r, uint32_t from, uint32_t to, Emit &&emit) {
+        uint32_t lo = low + r * from, h = low + r * to;
+        int shifted = 0;
+        for (;;) {
+            if ((lo ^ h) & kTopMask) {
+                if (h - lo > kRangeThreshold) break;
+                const uint32_t lim = h & kTopMask;
+                if (h - lim >= lim - lo) lo = lim; else h = lim - 1;
+            }
+            if (shifted == 4) return -1;
+            emit(static_cast<uint8_t>(lo >> 24));
+            ++shifted;
+            lo <<= 8;
+            h <<= 8;
+        }
+        low = lo;
+        hi = h;
+        return shifted;
+    }
+};
+
+class Encoder {
+public:
+    Encoder(uint8_t *out, size_t cap) : out_(out), cap_(cap) {}
+    // interval [from,to) out of total
+    inline bool put(uint32_t total, uint32_t from, uint32_t to) {
+        if (!(from < to && to <= total)) return fail(DK_E_INTERNAL);
+        const uint32_t r = (rs_.hi - rs_.low) / total;
+        if (r == 0) return fail(DK_E_INTERNAL);
+        return emit_narrow(r, from, to);
+    }
+    // same with total == 1 << shift (bin models with threshold 4096, apm::Bit): the division becomes a shift
+    inline bool put_pow2(unsigned shift, uint32_t from, uint32_t to) {
+        if (!(from < to && to <= (1u << shift))) return fail(DK_E_INTERNAL);
+        const uint32_t r = (rs_.hi - rs_.low) >> shift;
+        if (r == 0) return fail(DK_E_INTERNAL);
+        return emit_narrow(r, from, to);
+    }
+    bool finish() {  // ari::Encoder::finish: code tail = low, big-endian
+        if (len_ + 4 > cap_) return fail(DK_E_CAPACITY);
+        for (int i = 0; i < 4; ++i) out_[len_++] = static_cast<uint8_t>(rs_.low >> (24 - 8 * i));
+        return err_ == 0;
+    }
+    size_t size() const { return len_; }
+    int error() const { return err_; }
+
+private:
+    inline bool emit_narrow(uint32_t r, uint32_t from, uint32_t to) {
+        if (len_ + 4 > cap_) return fail(DK_E_CAPACITY);
+        uint8_t *p = out_ + len_;
+        int k = rs_.narrow(r, from, to, [&](uint8_t b) { *p++ = b; });
+        if (k < 0) return fail(DK_E_INTERNAL);
+        len_ += static_cast<size_t>(k);
+        return true;
+    }
+    bool fail(int e) { if (!err_) err_ = e; return false; }
+    RangeState rs_;
+    uint8_t *out_;
+    size_t cap_, len_ = 0;
+    int err_ = 0;
+};
+
+class Decoder {
+public:
+    Decoder(const uint8_t *in, size_t len) : in_(in), len_(len) {}
+    // offset of the code under `total`; the caller finds the symbol and then calls take()
+    inline uint32_t peek(uint32_t total) {
+        feed();
+        r_ = (rs_.hi - rs_.low) / total;
+        if (r_ == 0) { fail(DK_E_STREAM); return 0; }
+        return (code_ - rs_.low) / r_;
+    }
+    inline uint32_t peek_pow2(unsigned shift) {
+        feed();
+        r_ = (rs_.hi - rs_.low) >> shift;
+        if (r_ == 0) { fail(DK_E_STREAM); return 0; }
+        return (code_ - rs_.low) / r_;
+    }
+    inline bool take(uint32_t from, uint32_t to) {
+        int k = rs_.narrow(r_, from, to, [](uint8_t) {});
+        if (k < 0) return fail(DK_E_STREAM);
+        pending_ = k;
+        return err_ == 0;
+    }
+    bool finish() { feed(); return err_ == 0; }  // ari::Decoder::finish consumes the pending tail bytes
+    int error() const { return err_; }
+    bool fail(int e) { if (!err_) err_ = e; return false; }
+
+private:
+    inline void feed() {
+        while (pending_) {
+            uint8_t b = 0;
+            if (pos_ < len_) b = in_[pos_++]; else fail(DK_E_STREAM);  // read_u8 Err -> the reference unwraps (panics)
+            code_ = (code_ << 8) + b;
+            --pending_;
+        }
+    }
+    RangeState rs_;
+    const uint8_t *in_;
+    size_t len_, pos_ = 0;
+    uint32_t code_ = 0, r_ = 0;
+    int pending_ = 4;
+    int err_ = 0;
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// Frequency models: ari::table::Model (u16 counts, cut threshold, halving with round-up), ari::bin::Model
+// (probability of zero out of a fixed total, shift-rate adaptation), their SumProxy mixers, apm::Bit.
+// ------------------------------------------------------------------------------------------------------------------
+template <int N>
+struct FreqTable {
+    uint32_t total;
+    uint16_t f[N];
+    void flat() { for (int i = 0; i < N; ++i) f[i] = 1; total = N; while (total >= kModelThreshold) halve(); }
+    void halve() { total = 0; for (int i = 0; i < N; ++i) { f[i] = static_cast<uint16_t>((f[i] + 1) >> 1); total += f[i]; } }
+    inline void bump(size_t v, unsigned add_log, uint32_t add_const) {
+        const uint32_t add = (total >> add_log) + add_const;
+        f[v] = static_cast<uint16_t>(f[v] + add);
+        total += add;
+        if (total >= kModelThreshold) halve();
+    }
+    inline uint32_t below(size_t v) const { uint32_t s = 0; for (size_t i = 0; i < v; ++i) s += f[i]; return s; }
+    bool encode(Encoder &e, size_t v) const { const uint32_t lo = below(v); return e.put(total, lo, lo + f[v]); }
+    bool decode(Decoder &d, size_t &v) const {
+        const uint32_t off = d.peek(total);
+        if (off >= total) return d.fail(DK_E_STREAM);
+        uint32_t lo = 0, hi = f[0];
+        size_t k = 0;
+        while (hi <= off) { lo = hi; hi += f[++k]; }
+        v = k;
+        return d.take(lo, hi);
+    }
+};
+
+// table::SumProxy::new(1, a, 2, b, 0): the only weighting the reference uses (dark.rs:194,243)
+template <int N>
+inline bool encode_mix12(Encoder &e, const FreqTable<N> &a, const FreqTable<N> &b, size_t v) {
+    uint32_t lo = 0;
+    for (size_t i = 0; i < v; ++i) lo += a.f[i] + 2u * b.f[i];
+    return e.put(a.total + 2u * b.total, lo, lo + a.f[v] + 2u * b.f[v]);
+}
+template <int N>
+inline bool decode_mix12(Decoder &d, const FreqTable<N> &a, const FreqTable<N> &b, size_t &v) {
+    const uint32_t total = a.total + 2u * b.total;
+    const uint32_t off = d.peek(total);
+    if (off >= total) return d.fail(DK_E_STREAM);
+    uint32_t lo = 0, hi = a.f[0] + 2u * b.f[0];
+    size_t k = 0;
+    while (hi <= off) {
+        if (++k >= static_cast<size_t>(N)) return d.fail(DK_E_STREAM);
+        lo = hi;
+        hi += a.f[k] + 2u * b.f[k];
+    }
+    v = k;
+    return d.take(lo, hi);
+}
+
+struct BinFreq {  // total is always kModelThreshold = 1 << 12 in the reference's models
+    static constexpr unsigned kShift = 12;
+    uint32_t zero;
+    void flat() { zero = kModelThreshold >> 1; }
+    template <unsigned RATE> inline void learn(bool one) {
+        if (one) zero -= zero >> RATE; else zero += (kModelThreshold - zero) >> RATE;
+    }
+};
+static_assert((1u << BinFreq::kShift) == kModelThreshold, "bin total must be a power of two");
+inline bool encode_bit_p(Encoder &e, uint32_t zero, bool one) {
+    return one ? e.put_pow2(12, zero, 1u << 12) : e.put_pow2(12, 0, zero);
+}
+inline bool decode_bit_p(Decoder &d, uint32_t zero, bool &one) {
+    const uint32_t off = d.peek_pow2(12);
+    if (off >= (1u << 12)) return d.fail(DK_E_STREAM);
+    one = off >= zero;
+    return one ? d.take(zero, 1u << 12) : d.take(0, zero);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Distance models.  Interface = src/model/mod.rs:32-39 (reset / encode / decode); only Context.symbol matters to
+// them (dark.rs:184, exp.rs:61, ybs.rs:98).
+// ------------------------------------------------------------------------------------------------------------------
+inline unsigned bit_length(uint32_t v) { return v ? 32u - static_cast<unsigned>(__builtin_clz(v)) : 0u; }
+
+class DarkModel {  // src/model/dark.rs
+public:
+    DarkModel() { reset(); }
+    void reset();
+    bool encode(uint32_t dist, uint8_t symbol, Encoder &e);
+    bool decode(uint8_t symbol, Decoder &d, uint32_t &dist);
+
+private:
+    struct PerSymbol { int64_t avg_dist; FreqTable<8> log_freq; BinFreq extra[32]; };
+    inline void adapt(PerSymbol &c, uint32_t dist, int log_diff);
+    FreqTable<8> log_global_[12][3];
+    BinFreq log_bits_[2][32];
+    BinFreq mantissa_[32][4];
+    PerSymbol sym_[256];
+    unsigned last_token_;
+};
+
+class ExpModel {  // src/model/exp.rs
+public:
+    ExpModel() { reset(); }
+    void reset();
+    bool encode(uint32_t dist, uint8_t symbol, Encoder &e);
+    bool decode(uint8_t symbol, Decoder &d, uint32_t &dist);
+
+private:
+    static uint32_t log_fixed(uint32_t d);
+    uint32_t avg_log_[256];
+    uint16_t prob_[10][24];
+};
+
+class YbsModel {  // src/model/ybs.rs
+public:
+    YbsModel() { reset(); }
+    void reset();
+    bool encode(uint32_t dist, uint8_t symbol, Encoder &e);
+    bool decode(uint8_t symbol, Decoder &d, uint32_t &dist);
+
+private:
+    struct PerSymbol { uint32_t avg_log, last_diff; };
+    static void track(PerSymbol &c, uint32_t log);
+    FreqTable<14> low_[13];
+    FreqTable<19> high_;
+    BinFreq rest_[3];
+    PerSymbol sym_[256];
+};
+
+class SimpleModel {  // src/model/simple.rs
+public:
+    SimpleModel() { reset(); }
+    void reset();
+    bool encode(uint32_t dist, uint8_t symbol, Encoder &e);
+    bool decode(uint8_t symbol, Decoder &d, uint32_t &dist);
+
+private:
+    FreqTable<256> freq_[4];
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// Block stream (src/block/dc.rs) and friends
+// ------------------------------------------------------------------------------------------------------------------
+struct DcStream {          // what the GPU DC stage hands to the entropy stage
+    size_t n = 0;          // block size
+    const uint32_t *init = nullptr;     // [256] first position per symbol, n = absent
+    const uint32_t *dist = nullptr;     // [m]
+    const uint8_t *sym = nullptr;       // [m]
+    const uint8_t *rank = nullptr;      // [m] Context.last_rank   (RAWDC only)
+    const uint32_t *run_end = nullptr;  // [m] position of each entry (RAWDC only: distance_limit = n - pos)
+    size_t m = 0;
+    uint32_t origin = 0;
+};
+// src/block/dc.rs:53-90: init-table RLE header, distances, origin, finish
+int encode_block_stream(int model_id, const DcStream &s, uint8_t *out, size_t cap, size_t *out_len);
+// src/block/dc.rs:121-151: header, dc::decode pulling model.decode, origin.  *single = 1 when the block has a
+// one-symbol alphabet (the reference then mis-reads origin; see DESIGN.md "Reference quirks").
+int decode_block_stream(int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *bwt_out,
+                        uint32_t *origin, int *single);
+// compress::bwt::dc::decode fed from an array
+int dc_decode_array(const uint32_t init[256], const uint32_t *dist, size_t m, uint8_t *bwt_out, size_t n, size_t *consumed);
+// model-level helpers (src/model/mod.rs:59-76)
+int model_encode_stream(int model_id, const uint32_t *dist, const uint8_t *sym, size_t m, uint8_t *out, size_t cap, size_t *out_len);
+int model_decode_stream(int model_id, const uint8_t *in, size_t in_len, const uint8_t *sym, size_t m, uint32_t *dist);
+// src/entropy/{mod,ari}.rs
+int bitcoder_encode(const uint8_t *bits, const uint16_t *flat, size_t nbits, uint8_t *out, size_t cap, size_t *out_len);
+int bitcoder_decode(const uint8_t *in, size_t in_len, const uint16_t *flat, size_t nbits, uint8_t *bits);
+// largest n a model can code without losing bits (0 = unknown model)
+uint64_t model_max_block(int model_id);
+
+}  // namespace dk

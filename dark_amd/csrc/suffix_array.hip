@@ -1,0 +1,307 @@
+// Suffix array by GPU prefix doubling over the device radix sort.  Replaces saca::Constructor::compute
+// (src/saca.rs:368-378) and with it all of saca() (src/saca.rs:270-340); the result is the same array: the suffix
+// array is unique, and like the reference there is no sentinel -- a suffix that is a proper prefix of another sorts first.
+//
+//   1. k_sym_hist        byte histogram -> host picks an order-preserving code of b = ceil(log2 sigma) bits per symbol
+//   2. k_pack_keys       key[i] = the first s = floor(64/b) symbols of suffix i, packed big-endian, zero padded
+//   3. sort_pairs        (key, i) by key                                  -> order by the first s symbols
+//   4. rerank            heads where the key changes; rank[i] = position of its group's head; singletons are final
+//                        (written to SA), the rest are compacted into the ACTIVE list (idx, slot position, group id)
+//   5. while active:     key = (group id, rank2) with rank2 = rank[i+h]+h, or n-1-i for i+h >= n (shorter is smaller);
+//                        sort_pairs on exactly the bits in use; rerank; h *= 2
+// Only members of unresolved groups are ever sorted again (Larsson-Sadakane style filtering).
+#include "context.hpp"
+#include "device_util.hpp"
+
+namespace dk {
+namespace {
+
+constexpr int RR_BLOCK = 256;
+constexpr int RR_WAVES = RR_BLOCK / 64;
+constexpr int RR_IPT = 8;                    // slots per thread (contiguous)
+constexpr int RR_TILE = RR_BLOCK * RR_IPT;   // 2048 slots per workgroup
+
+__global__ __launch_bounds__(256) void k_sym_hist(const uint8_t *__restrict__ t, size_t n, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) atomicAdd(&h[t[i]], 1u);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_pack_keys(const uint8_t *__restrict__ t, size_t n, const uint8_t *__restrict__ code,
+                                                    int bits, int spk, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx) {
+    __shared__ uint8_t s_code[256];
+    s_code[threadIdx.x] = code[threadIdx.x];
+    __syncthreads();
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t key = 0;
+    for (int j = 0; j < spk; ++j) {
+        const size_t p = i + j;
+        const uint64_t c = p < n ? s_code[t[p]] : 0;
+        key = (key << bits) | c;
+    }
+    keys[i] = key;
+    idx[i] = static_cast<uint32_t>(i);
+}
+
+__global__ __launch_bounds__(256) void k_sa_descending(uint32_t *__restrict__ sa, size_t n) {
+    const size_t j = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (j < n) sa[j] = static_cast<uint32_t>(n - 1 - j);
+}
+
+// ---- rerank: three kernels sharing the per-slot flag logic ------------------------------------------------------
+struct RerankAgg { uint32_t surv, heads, last_head, pad; };
+
+// flags of the RR_IPT slots starting at a0: head[j] = key differs from its predecessor (slot 0 is a head);
+// surv[j] = the slot's group has more than one member
+__device__ __forceinline__ void slot_flags(const uint64_t *__restrict__ keys, size_t count, size_t a0, bool head[RR_IPT],
+                                           bool surv[RR_IPT]) {
+    uint64_t k[RR_IPT + 2];
+#pragma unroll
+    for (int j = 0; j < RR_IPT + 2; ++j) {
+        const size_t a = a0 + j;  // k[j] = key of slot a0 + j - 1
+        k[j] = (a >= 1 && a - 1 < count) ? keys[a - 1] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < RR_IPT; ++j) {
+        const size_t a = a0 + j;
+        head[j] = a < count && (a == 0 || k[j + 1] != k[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < RR_IPT; ++j) {
+        const size_t a = a0 + j;
+        const bool next_head = (a + 1 >= count) || (k[j + 2] != k[j + 1]);
+        surv[j] = a < count && !(head[j] && next_head);
+    }
+}
+
+__global__ __launch_bounds__(RR_BLOCK) void k_rerank_reduce(const uint64_t *__restrict__ keys, size_t count,
+                                                             RerankAgg *__restrict__ agg) {
+    __shared__ uint32_t s_red[3][RR_WAVES];
+    const size_t a0 = static_cast<size_t>(blockIdx.x) * RR_TILE + static_cast<size_t>(threadIdx.x) * RR_IPT;
+    bool head[RR_IPT], surv[RR_IPT];
+    slot_flags(keys, count, a0, head, surv);
+    uint32_t ns = 0, nh = 0, lh = 0;
+#pragma unroll
+    for (int j = 0; j < RR_IPT; ++j) {
+        ns += surv[j];
+        nh += head[j] && surv[j];
+        if (head[j]) lh = static_cast<uint32_t>(a0 + j);
+    }
+    ns = wave_sum(ns);
+    nh = wave_sum(nh);
+    lh = wave_max(lh);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_red[0][wave] = ns; s_red[1][wave] = nh; s_red[2][wave] = lh; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        RerankAgg r{0, 0, 0, 0};
+        for (int w = 0; w < RR_WAVES; ++w) {
+            r.surv += s_red[0][w];
+            r.heads += s_red[1][w];
+            r.last_head = r.last_head > s_red[2][w] ? r.last_head : s_red[2][w];
+        }
+        agg[blockIdx.x] = r;
+    }
+}
+
+// one workgroup: exclusive scan of the per-tile aggregates (sum, sum, running max); totals -> mail[0..1]
+__global__ __launch_bounds__(1024) void k_rerank_scan(RerankAgg *__restrict__ agg, size_t ntiles, uint32_t *__restrict__ mail) {
+    __shared__ uint32_t s_tmp[16 + 1];
+    const int tid = threadIdx.x;
+    const size_t per = (ntiles + 1023) / 1024;
+    const size_t b0 = static_cast<size_t>(tid) * per;
+    const size_t b1 = b0 + per < ntiles ? b0 + per : ntiles;
+    uint32_t ns = 0, nh = 0, lh = 0;
+    for (size_t b = b0; b < b1; ++b) {
+        const RerankAgg r = agg[b];
+        ns += r.surv;
+        nh += r.heads;
+        lh = lh > r.last_head ? lh : r.last_head;
+    }
+    uint32_t tot_s, tot_h;
+    uint32_t es = block_excl_sum<16>(ns, s_tmp, &tot_s);
+    uint32_t eh = block_excl_sum<16>(nh, s_tmp, &tot_h);
+    uint32_t el = block_excl_max<16>(lh, s_tmp, nullptr);
+    for (size_t b = b0; b < b1; ++b) {
+        const RerankAgg r = agg[b];
+        agg[b] = RerankAgg{es, eh, el, 0};
+        es += r.surv;
+        eh += r.heads;
+        el = el > r.last_head ? el : r.last_head;
+    }
+    if (tid == 0) { mail[0] = tot_s; mail[1] = tot_h; }
+}
+
+// pos_in == nullptr means slot a sits at SA position a (first rerank, straight after the initial sort)
+__global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx,
+                                                            const uint32_t *__restrict__ pos_in, size_t count,
+                                                            const RerankAgg *__restrict__ agg, uint32_t *__restrict__ rank,
+                                                            uint32_t *__restrict__ sa, uint32_t *__restrict__ out_idx,
+                                                            uint32_t *__restrict__ out_pos, uint32_t *__restrict__ out_gid) {
+    __shared__ uint32_t s_tmp[RR_WAVES + 1];
+    const size_t a0 = static_cast<size_t>(blockIdx.x) * RR_TILE + static_cast<size_t>(threadIdx.x) * RR_IPT;
+    bool head[RR_IPT], surv[RR_IPT];
+    slot_flags(keys, count, a0, head, surv);
+    uint32_t ns = 0, nh = 0, lh = 0;
+#pragma unroll
+    for (int j = 0; j < RR_IPT; ++j) {
+        ns += surv[j];
+        nh += head[j] && surv[j];
+        if (head[j]) lh = static_cast<uint32_t>(a0 + j);
+    }
+    const RerankAgg base = agg[blockIdx.x];
+    uint32_t es = base.surv + block_excl_sum<RR_WAVES>(ns, s_tmp, nullptr);
+    uint32_t eh = base.heads + block_excl_sum<RR_WAVES>(nh, s_tmp, nullptr);
+    uint32_t el = block_excl_max<RR_WAVES>(lh, s_tmp, nullptr);
+    el = el > base.last_head ? el : base.last_head;
+#pragma unroll
+    for (int j = 0; j < RR_IPT; ++j) {
+        const size_t a = a0 + j;
+        if (a >= count) break;
+        if (head[j]) el = static_cast<uint32_t>(a);
+        const uint32_t suffix = idx[a];
+        const uint32_t my_pos = pos_in ? pos_in[a] : static_cast<uint32_t>(a);
+        const uint32_t head_pos = pos_in ? pos_in[el] : el;
+        rank[suffix] = head_pos;
+        if (!surv[j]) {
+            sa[my_pos] = suffix;  // the group is a singleton: this suffix is in its final place
+        } else {
+            if (head[j]) ++eh;
+            out_idx[es] = suffix;
+            out_pos[es] = my_pos;
+            out_gid[es] = eh - 1;
+            ++es;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_build_keys(const uint32_t *__restrict__ act_idx, const uint32_t *__restrict__ act_gid,
+                                                     const uint32_t *__restrict__ rank, uint32_t n, uint32_t h, int kbits,
+                                                     uint64_t *__restrict__ keys, size_t count) {
+    const size_t a = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (a >= count) return;
+    const uint64_t p = static_cast<uint64_t>(act_idx[a]) + h;
+    // rank of the suffix h symbols further on, shifted up by h; suffixes that end before that get n-1-i (< h), which
+    // orders them among themselves by "shorter first" and in front of every suffix that continues
+    const uint32_t r2 = p < n ? rank[p] + h : static_cast<uint32_t>(static_cast<uint64_t>(n) + h - 1 - p);
+    keys[a] = (static_cast<uint64_t>(act_gid[a]) << kbits) | r2;
+}
+
+int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_t *pos_in, size_t count, uint32_t *rank,
+           uint32_t *sa, uint32_t *out_idx, uint32_t *out_pos, uint32_t *out_gid, size_t *active, size_t *groups) {
+    const size_t ntiles = div_up(count, RR_TILE);
+    const size_t mark = ctx->ws_mark();
+    RerankAgg *agg = ctx->ws_alloc<RerankAgg>(ntiles);
+    if (!agg) return DK_E_NOMEM;
+    hipStream_t st = ctx->stream;
+    {
+        LaunchScope ls(ctx, K_RERANK_REDUCE, 8.0 * count);
+        k_rerank_reduce<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, count, agg);
+    }
+    {
+        LaunchScope ls(ctx, K_RERANK_SCAN, 32.0 * ntiles);
+        k_rerank_scan<<<dim3(1), dim3(1024), 0, st>>>(agg, ntiles, ctx->d_mail);
+    }
+    {
+        LaunchScope ls(ctx, K_RERANK_APPLY, 8.0 * count + 4.0 * count + 4.0 * count + 12.0 * count);
+        k_rerank_apply<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, agg, rank, sa, out_idx, out_pos, out_gid);
+    }
+    DK_HIP(ctx, hipGetLastError());
+    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    DK_HIP(ctx, hipStreamSynchronize(st));
+    *active = ctx->h_mail[0];
+    *groups = ctx->h_mail[1];
+    ctx->ws_release(mark);
+    return DK_OK;
+}
+
+}  // namespace
+
+int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_sa) {
+    if (n == 0 || n > 0x7FFFFFFEull) return ctx->fail(DK_E_ARG, "suffix_array: n out of range");
+    hipStream_t st = ctx->stream;
+    ctx->stats.rounds = 0;
+    ctx->stats.sort_passes = 0;
+    ctx->stats.sorted_elements = 0;
+    const size_t mark = ctx->ws_mark();
+
+    // 1. alphabet
+    uint32_t *d_hist = ctx->d_mail + 16;
+    DK_HIP(ctx, hipMemsetAsync(d_hist, 0, 256 * sizeof(uint32_t), st));
+    {
+        LaunchScope ls(ctx, K_SYM_HIST, 1.0 * n);
+        const size_t blocks = std::min<size_t>(div_up(n, 256 * 16), 2048);
+        k_sym_hist<<<dim3(blocks), dim3(256), 0, st>>>(d_text, n, d_hist);
+    }
+    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 16, d_hist, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    DK_HIP(ctx, hipStreamSynchronize(st));
+    uint8_t code[256];
+    unsigned sigma = 0;
+    for (int s = 0; s < 256; ++s) {
+        code[s] = static_cast<uint8_t>(sigma);
+        if (ctx->h_mail[16 + s]) ++sigma;
+    }
+    if (sigma <= 1) {  // one distinct symbol: suffixes sort by length
+        k_sa_descending<<<dim3(div_up(n, 256)), dim3(256), 0, st>>>(d_sa, n);
+        DK_HIP(ctx, hipGetLastError());
+        return DK_OK;
+    }
+    const int bits = static_cast<int>(ceil_log2_u64(sigma));  // 1..8
+    const int spk = 64 / bits;                                // symbols per key: 8 (bytes) .. 32 (ACGT) .. 64 (binary)
+
+    uint64_t *keys = ctx->ws_alloc<uint64_t>(n), *keys_alt = ctx->ws_alloc<uint64_t>(n);
+    uint32_t *vals = ctx->ws_alloc<uint32_t>(n), *vals_alt = ctx->ws_alloc<uint32_t>(n);
+    uint32_t *rank = ctx->ws_alloc<uint32_t>(n);
+    uint32_t *pos = ctx->ws_alloc<uint32_t>(n), *pos_alt = ctx->ws_alloc<uint32_t>(n);
+    uint32_t *gid = ctx->ws_alloc<uint32_t>(n), *gid_alt = ctx->ws_alloc<uint32_t>(n);
+    uint8_t *d_code = reinterpret_cast<uint8_t *>(ctx->d_mail + 512);
+    if (!keys || !keys_alt || !vals || !vals_alt || !rank || !pos || !pos_alt || !gid || !gid_alt) return DK_E_NOMEM;
+    DK_HIP(ctx, hipMemcpyAsync(d_code, code, 256, hipMemcpyHostToDevice, st));
+
+    // 2.-3. initial keys and sort
+    {
+        LaunchScope ls(ctx, K_PACK_KEYS, 1.0 * n + 12.0 * n);
+        k_pack_keys<<<dim3(div_up(n, 256)), dim3(256), 0, st>>>(d_text, n, d_code, bits, spk, keys, vals);
+    }
+    DK_HIP(ctx, hipGetLastError());
+    DK_TRY(sort_pairs(ctx, keys, keys_alt, vals, vals_alt, n, 0, bits * spk));
+
+    // 4. first rerank (slots are SA positions)
+    size_t active = 0, groups = 0;
+    DK_TRY(rerank(ctx, keys, vals, nullptr, n, rank, d_sa, vals_alt, pos, gid, &active, &groups));
+    std::swap(vals, vals_alt);  // vals = suffix indices of the active list
+
+    // 5. doubling rounds
+    uint64_t h = static_cast<uint64_t>(spk);
+    while (active > 0) {
+        if (ctx->stats.rounds > 40) return ctx->fail(DK_E_INTERNAL, "suffix_array: no convergence after 40 rounds");
+        const uint32_t h_eff = static_cast<uint32_t>(std::min<uint64_t>(h, n));
+        const int kbits = static_cast<int>(ceil_log2_u64(static_cast<uint64_t>(n) + h_eff));
+        const int gbits = static_cast<int>(ceil_log2_u64(groups));
+        {
+            LaunchScope ls(ctx, K_BUILD_KEYS, 8.0 * active + 4.0 * active + 8.0 * active);
+            k_build_keys<<<dim3(div_up(active, 256)), dim3(256), 0, st>>>(vals, gid, rank, static_cast<uint32_t>(n), h_eff, kbits,
+                                                                         keys, active);
+        }
+        DK_HIP(ctx, hipGetLastError());
+        DK_TRY(sort_pairs(ctx, keys, keys_alt, vals, vals_alt, active, 0, kbits + gbits));
+        size_t next_active = 0, next_groups = 0;
+        DK_TRY(rerank(ctx, keys, vals, pos, active, rank, d_sa, vals_alt, pos_alt, gid_alt, &next_active, &next_groups));
+        std::swap(vals, vals_alt);
+        std::swap(pos, pos_alt);
+        std::swap(gid, gid_alt);
+        active = next_active;
+        groups = next_groups;
+        ctx->stats.rounds += 1;
+        h *= 2;
+    }
+    ctx->ws_release(mark);
+    return DK_OK;
+}
+
+}  // namespace dk

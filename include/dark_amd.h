@@ -1,0 +1,142 @@
+/* dark_amd.h -- C ABI of the MI355X-native BWT compression path that drops in for kvark/dark's
+ * src/saca.rs + src/block + src/model + src/entropy.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the reference root).
+ * Conventions (mirroring the reference's `&mut self` objects):
+ *   - a dk_ctx is owned by one host thread and one GPU; it is NOT thread-safe; distinct contexts may run
+ *     concurrently on distinct threads / GPUs;
+ *   - all functions return DK_OK (0) or a negative DK_E_* code and never unwind or abort across the boundary;
+ *     dk_last_error() gives the text of the last failure on that context;
+ *   - "host" entry points take caller-owned host pointers valid for the call; "dk_dev_" entry points take
+ *     caller-owned DEVICE pointers (hipMalloc'ed on the context's GPU, e.g. torch tensor .data_ptr());
+ *   - n == 0 is an error (the reference panics at src/saca.rs:107); n must be <= dk_capacity();
+ *   - there is no CPU fallback: without a GPU dk_ctx_create fails.  Suffix sorting, BWT, DC distances and
+ *     the inverse BWT run on the GPU; the adaptive range coder and dc::decode are serial by construction
+ *     (every symbol updates the model the next one reads) and run on the host inside this library.
+ */
+#ifndef DARK_AMD_H
+#define DARK_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DK_OK 0
+#define DK_E_ARG (-1)        /* null pointer, n == 0, n > capacity, origin out of range ... */
+#define DK_E_NOMEM (-2)      /* host or device allocation failed */
+#define DK_E_HIP (-3)        /* HIP runtime error (text in dk_last_error) */
+#define DK_E_CAPACITY (-4)   /* caller's output buffer is too small */
+#define DK_E_MODEL (-5)      /* unknown model id, or the model cannot represent a value at this block size */
+#define DK_E_STREAM (-6)     /* corrupt / truncated stream, or a stream the reference format cannot decode */
+#define DK_E_INTERNAL (-7)   /* invariant violated (bug) */
+#define DK_E_NODEVICE (-8)   /* no usable GPU: this library has no CPU backend */
+
+/* model ids = the -m names of src/main.rs:73-82 */
+#define DK_MODEL_DARK 0   /* src/model/dark.rs   (valid for every block size < 2^31) */
+#define DK_MODEL_EXP 1    /* src/model/exp.rs    (CLI default; distances truncated to 24 bits: n <= 2^24) */
+#define DK_MODEL_YBS 2    /* src/model/ybs.rs    (distances < 2^29) */
+#define DK_MODEL_SIMPLE 3 /* src/model/simple.rs (distances < 2^24 + 255) */
+#define DK_MODEL_RAWDC 4  /* src/model/raw.rs:12-44 DcOut: 10-byte records instead of a coded stream */
+
+typedef struct dk_ctx dk_ctx;
+
+/* saca::Constructor::new(max_n) src/saca.rs:351-360 + block::dc::{Encoder,Decoder}::new src/block/dc.rs:30-37,106-115.
+ * Allocates the device workspace for blocks of up to max_n bytes on GPU `hip_device` (>= 0). */
+int dk_ctx_create(int hip_device, size_t max_n, dk_ctx **out);
+void dk_ctx_destroy(dk_ctx *ctx);
+/* saca::Constructor::capacity src/saca.rs:363-365 */
+size_t dk_capacity(const dk_ctx *ctx);
+const char *dk_last_error(const dk_ctx *ctx);
+/* library / build identification, e.g. "dark_amd 0.1 gfx950" */
+const char *dk_version(void);
+
+/* ---- host-pointer entry points ------------------------------------------------------------------------- */
+/* saca::Constructor::compute src/saca.rs:368-378: sa_out[0..n) = suffix array of in[0..n)
+ * (no sentinel; a suffix that is a prefix of another sorts first). */
+int dk_suffix_array(dk_ctx *ctx, const uint8_t *in, size_t n, uint32_t *sa_out);
+/* compress::bwt::TransformIterator as driven by src/block/dc.rs:45-50: bwt_out[i] = in[SA[i]-1] (in[n-1] where
+ * SA[i]==0), *origin = the i with SA[i]==0.  Known answers src/saca.rs:411-412. */
+int dk_bwt_forward(dk_ctx *ctx, const uint8_t *in, size_t n, uint8_t *bwt_out, uint32_t *origin);
+/* compress::bwt::decode as driven by src/block/dc.rs:154-156 */
+int dk_bwt_inverse(dk_ctx *ctx, const uint8_t *bwt, size_t n, uint32_t origin, uint8_t *out);
+/* compress::bwt::dc::encode + EncodeIterator as driven by src/block/dc.rs:52,82-85, compacted: one entry per run
+ * of the BWT, in position order.  init[s] = first position of s, or n if absent.  dist/sym/rank hold up to n
+ * entries (rank = Context.last_rank, may be NULL); *m = number of entries. */
+int dk_dc_encode(dk_ctx *ctx, const uint8_t *bwt, size_t n, uint32_t init[256],
+                 uint32_t *dist, uint8_t *sym, uint8_t *rank, size_t *m);
+/* compress::bwt::dc::decode as driven by src/block/dc.rs:146-150 (host, serial).  *consumed (may be NULL) = number of
+ * distances read. */
+int dk_dc_decode(dk_ctx *ctx, const uint32_t init[256], const uint32_t *dist, size_t m,
+                 uint8_t *bwt_out, size_t n, size_t *consumed);
+/* block::Encoder::encode for block::dc::Encoder<M> src/block/dc.rs:41-91.  Output = the coded stream WITHOUT the
+ * u32 n header that src/main.rs:102 writes in front of it. */
+int dk_block_encode(dk_ctx *ctx, int model_id, const uint8_t *in, size_t n,
+                    uint8_t *out, size_t out_cap, size_t *out_len);
+/* block::Decoder::decode for block::dc::Decoder<M> src/block/dc.rs:119-160 */
+int dk_block_decode(dk_ctx *ctx, int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *out);
+
+/* ---- device-resident entry points (inputs already in HBM; used by pipelines and by bench.py) ----------------- */
+int dk_dev_suffix_array(dk_ctx *ctx, const uint8_t *d_in, size_t n, uint32_t *d_sa_out);
+int dk_dev_bwt_forward(dk_ctx *ctx, const uint8_t *d_in, size_t n, uint8_t *d_bwt_out, uint32_t *origin);
+int dk_dev_bwt_inverse(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t origin, uint8_t *d_out);
+/* d_dist/d_sym/d_rank: device arrays of n entries (d_rank may be NULL); init and m are returned on the host */
+int dk_dev_dc_encode(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t init[256],
+                     uint32_t *d_dist, uint8_t *d_sym, uint8_t *d_rank, size_t *m);
+/* whole forward path from a device-resident block to the coded stream in host memory */
+int dk_dev_block_encode(dk_ctx *ctx, int model_id, const uint8_t *d_in, size_t n,
+                        uint8_t *out, size_t out_cap, size_t *out_len);
+/* whole inverse path from a coded stream in host memory to a device-resident block */
+int dk_dev_block_decode(dk_ctx *ctx, int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *d_out);
+
+/* ---- model / coder level (host; what src/model/mod.rs:59-76 and src/entropy/ari.rs:76-107 exercise) ----------- */
+/* model.reset(); for k: model.encode(dist[k], Context{symbol: sym[k]}, eh); eh.finish()   (src/model/mod.rs:59-66) */
+int dk_model_encode(int model_id, const uint32_t *dist, const uint8_t *sym, size_t m,
+                    uint8_t *out, size_t out_cap, size_t *out_len);
+/* model.reset(); for k: dist[k] = model.decode(Context{symbol: sym[k]}, dh)              (src/model/mod.rs:67-75) */
+int dk_model_decode(int model_id, const uint8_t *in, size_t in_len, const uint8_t *sym, size_t m, uint32_t *dist);
+/* entropy::Encoder over entropy::ari::Range (src/entropy/mod.rs:11-41, src/entropy/ari.rs:8-74):
+ * bits[k] in {0,1}; flat[k] = apm::Bit::to_flat() = 12-bit probability of a zero */
+int dk_bitcoder_encode(const uint8_t *bits, const uint16_t *flat, size_t nbits,
+                       uint8_t *out, size_t out_cap, size_t *out_len);
+int dk_bitcoder_decode(const uint8_t *in, size_t in_len, const uint16_t *flat, size_t nbits, uint8_t *bits);
+
+/* Host entropy stage on its own (what the GPU stages feed): src/block/dc.rs:53-90 from (init, dist[m], sym[m], origin) to the
+ * coded stream, and src/block/dc.rs:121-151 back to (BWT, origin).  rank/run_end (Context.last_rank and the position of each
+ * entry) are only read by DK_MODEL_RAWDC and may be NULL otherwise.  *single_symbol = 1 flags a one-symbol block, for which the
+ * reference mis-reads `origin` (DESIGN.md "Reference quirks"). */
+int dk_stream_encode(int model_id, size_t n, const uint32_t init[256], const uint32_t *dist, const uint8_t *sym,
+                     const uint8_t *rank, const uint32_t *run_end, size_t m, uint32_t origin,
+                     uint8_t *out, size_t out_cap, size_t *out_len);
+int dk_stream_decode(int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *bwt_out, uint32_t *origin,
+                     int *single_symbol);
+
+/* ---- measurement ------------------------------------------------------------------------------------------ */
+#define DK_NUM_KERNEL_SLOTS 24
+typedef struct dk_stats {
+    /* wall-clock stage times of the last block call on this context, milliseconds */
+    double ms_h2d, ms_sa, ms_bwt, ms_dc, ms_d2h, ms_entropy, ms_ibwt, ms_total;
+    uint32_t rounds;          /* prefix-doubling rounds executed by the last suffix sort */
+    uint32_t sort_passes;     /* radix passes executed by the last suffix sort */
+    uint64_t sorted_elements; /* sum over passes of elements moved */
+    uint64_t dc_runs;         /* m of the last dc encode */
+    /* per-kernel HIP-event timings accumulated since dk_stats_reset (only while profiling is enabled) */
+    uint32_t kernel_launches[DK_NUM_KERNEL_SLOTS];
+    double kernel_ms[DK_NUM_KERNEL_SLOTS];
+    double kernel_bytes[DK_NUM_KERNEL_SLOTS]; /* algorithmic bytes summed over launches */
+} dk_stats;
+/* enable (1) / disable (0) HIP-event bracketing of every kernel launch on the context's stream */
+int dk_set_profiling(dk_ctx *ctx, int enabled);
+int dk_stats_reset(dk_ctx *ctx);
+int dk_get_stats(const dk_ctx *ctx, dk_stats *out);
+/* name of kernel slot i (NULL past the end) */
+const char *dk_kernel_name(int slot);
+
+/* ---- stage-level debug entry points used by the parity tests ------------------------------------------------ */
+/* stable LSD radix sort of (u64 key, u32 value) pairs on bits [begin_bit, end_bit) -- the workhorse of the suffix sort */
+int dk_dbg_sort_pairs(dk_ctx *ctx, uint64_t *keys, uint32_t *vals, size_t count, int begin_bit, int end_bit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DARK_AMD_H */

@@ -1,0 +1,149 @@
+"""CPU tests of the product library: it loads, exports every symbol include/dark_amd.h declares, refuses to run without a
+GPU, and its host entropy stage (range coder, models, stream layout, dc::decode, bitwise coder) is bit-exact with the oracle.
+No device compute is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import dark_amd
+from dark_amd import _lib, entropy, model
+from conftest import ROOT, seeded_inputs
+
+MODELS = ("dark", "exp", "ybs", "simple")
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "dark_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = dark_amd.load_library()
+    names = header_functions()
+    assert len(names) >= 28
+    for name in names:
+        assert hasattr(lib, name), "libdark_amd.so lacks %s" % name
+        assert name in _lib.SIGNATURES, "python binding lacks %s" % name
+    assert sorted(_lib.SIGNATURES) == names
+    assert b"gfx950" in lib.dk_version()
+
+
+def test_no_cpu_backend():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(dark_amd.DarkError) as e:
+        dark_amd.Context(1000)
+    assert e.value.code == _lib.DK_E_NODEVICE
+    lib = dark_amd.load_library()
+    h = C.c_void_p()
+    assert lib.dk_ctx_create(-1, 1000, C.byref(h)) == _lib.DK_E_NODEVICE  # -1 ("CPU") is not a backend
+    assert lib.dk_ctx_create(0, 0, C.byref(h)) == _lib.DK_E_ARG
+
+
+@pytest.mark.parametrize("m", MODELS)
+def test_model_streams_match_oracle(orc, vectors, m):
+    # src/model/mod.rs:112-120 roundtrips_dc: the fixed 4-tuple vector, then 1000 random (dist < 200, sym) pairs
+    g = vectors["oracle"]["model_mod_rs_113"]
+    assert model.encode(m, g["d"], g["sym"]).hex() == g["streams_hex"][m]
+    rng = np.random.default_rng(13)
+    for size, hi in ((1000, 200), (5000, 1 << 16), (3000, 1 << 23)):
+        d = rng.integers(0, hi, size=size, dtype=np.uint32)
+        sym = rng.integers(0, 256, size=size, dtype=np.uint8)
+        s = model.encode(m, d, sym)
+        assert s == orc.model_encode(m, d, sym)
+        assert (model.decode(m, s, sym) == d).all()
+
+
+def test_dark_model_wide_distances(orc):
+    rng = np.random.default_rng(17)
+    d = (rng.integers(0, 2**31 - 2, size=4000, dtype=np.int64) >> rng.integers(0, 31, size=4000)).astype(np.uint32)
+    d[:4] = [0, 1, 2**31 - 2, 2**30]
+    sym = rng.integers(0, 256, size=4000, dtype=np.uint8)
+    s = model.encode("dark", d, sym)
+    assert s == orc.model_encode("dark", d, sym)
+    assert (model.decode("dark", s, sym) == d).all()
+    with pytest.raises(dark_amd.DarkError):  # dist+1 would need 32 significant bits: dark.rs:132 has 32 mantissa rows
+        model.encode("dark", [2**31 - 1], [0])
+
+
+@pytest.mark.parametrize("name", ["abracababra", "LICENSE"])
+def test_entropy_stage_against_golden(orc, vectors, license_bytes, name):
+    data = b"abracababra" if name == "abracababra" else license_bytes
+    g = vectors["oracle"][name]
+    bwt = bytes.fromhex(g["bwt_hex"])
+    dc = orc.dc_encode(bwt)
+    ends = np.flatnonzero(dc["sparse"] != len(data)).astype(np.uint32)
+    for m in MODELS:
+        s = model.stream_encode(m, len(data), dc["init"], dc["d"], dc["sym"], g["origin"])
+        assert s.hex() == g["streams_hex"][m]
+        b2, o2, single = model.stream_decode(m, s, len(data))
+        assert b2.tobytes() == bwt and o2 == g["origin"] and not single
+    rec = model.stream_encode("rawdc", len(data), dc["init"], dc["d"], dc["sym"], g["origin"], rank=dc["rank"], run_end=ends)
+    assert rec.hex() == g["rawdc_records_hex"]
+
+
+def test_entropy_stage_seeded(orc):
+    for t in seeded_inputs(seed=23, count=40):
+        n = len(t)
+        if n == 1:
+            continue
+        bwt, origin = orc.bwt_forward(t)
+        dc = orc.dc_encode(bwt)
+        for m in MODELS:
+            s = model.stream_encode(m, n, dc["init"], dc["d"], dc["sym"], origin)
+            assert s == orc.block_dc_encode_bwt(m, bwt, origin)
+            if (bwt == 255).any():
+                continue  # header cannot carry symbol 0xFF (block/dc.rs:57-73): undecodable by design
+            b2, o2, single = model.stream_decode(m, s, n)
+            assert (b2 == bwt).all()
+            assert single == (len(set(bwt.tolist())) == 1)
+            if not single:
+                assert o2 == origin
+
+
+def test_dc_decode_host(orc):
+    lib = dark_amd.load_library()
+    for t in seeded_inputs(seed=29, count=30):
+        if (t == 255).any():
+            continue
+        dc = orc.dc_encode(t)  # any byte string is a valid "BWT" for DC
+        init = np.ascontiguousarray(dc["init"], dtype=np.uint32)
+        d = np.ascontiguousarray(dc["d"], dtype=np.uint32)
+        out = np.empty(len(t), dtype=np.uint8)
+        used = C.c_size_t(0)
+        rc = lib.dk_dc_decode(None, init.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), len(d),
+                              out.ctypes.data_as(C.c_void_p), len(t), C.byref(used))
+        assert rc == 0 and (out == t).all()
+        ref, ref_used = orc.dc_decode(dc["init"], dc["d"], len(t))
+        assert used.value == ref_used
+
+
+def test_stream_errors():
+    with pytest.raises(dark_amd.DarkError) as e:
+        model.stream_decode("dark", b"\x00\x01", 100)
+    assert e.value.code == _lib.DK_E_STREAM
+    with pytest.raises(dark_amd.DarkError) as e:
+        model.encode("nope", [1], [1])
+    assert e.value.code == _lib.DK_E_MODEL
+    init = np.full(256, 1 << 25, dtype=np.uint32)
+    init[65] = 0
+    with pytest.raises(dark_amd.DarkError) as e:  # exp codes 24 bits only (exp.rs:22,67): refuse n > 2^24
+        model.stream_encode("exp", 1 << 25, init, [(1 << 25) - 1], [65], 3)
+    assert e.value.code == _lib.DK_E_MODEL
+
+
+def test_bitcoder_matches_oracle(orc, vectors):
+    g = vectors["oracle"]["entropy_ari_range"]
+    bits = [(b >> i) & 1 for b in g["bytes"] for i in range(8)]
+    assert entropy.encode_bits(bits, [g["flat"]] * 32).hex() == g["stream_hex"]
+    rng = np.random.default_rng(31)
+    flat = rng.integers(1, 4095, size=20000, dtype=np.uint16)
+    bits = (rng.integers(0, 4096, size=20000) >= flat).astype(np.uint8)
+    s = entropy.encode_bits(bits, flat)
+    assert s == orc.bitcoder_encode(bits, flat)
+    assert (entropy.decode_bits(s, flat) == bits).all()

@@ -1,0 +1,176 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same seeded inputs.
+Bit-exact everywhere (all stages are integer / byte / index work)."""
+import numpy as np
+import pytest
+
+import dark_amd
+from conftest import seeded_inputs
+
+pytestmark = pytest.mark.gpu
+MODELS = ("dark", "exp", "ybs", "simple")
+CAP = 6 << 20
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = dark_amd.Context(CAP)
+    yield c
+    c.close()
+
+
+def first_diff(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if len(a) != len(b):
+        return "len %d vs %d" % (len(a), len(b))
+    bad = np.flatnonzero(a != b)
+    if len(bad) == 0:
+        return None
+    i = int(bad[0])
+    return "%d mismatches, first at %d: got %s want %s" % (len(bad), i, a[i:i + 8], b[i:i + 8])
+
+
+def text_like(rng, n, vocab=2000):
+    words = [bytes(rng.integers(97, 123, size=int(rng.integers(1, 10)), dtype=np.uint8)) for _ in range(vocab)]
+    ids = rng.zipf(1.25, size=n // 3 + 16) % vocab
+    out = b" ".join(words[int(i)] for i in ids)
+    return np.frombuffer(out[:n], dtype=np.uint8)
+
+
+def test_sort_pairs(ctx):
+    rng = np.random.default_rng(1)
+    for count, lo, hi in ((1, 0, 64), (2, 0, 64), (257, 0, 64), (4096, 0, 64), (4097, 0, 64), (100003, 0, 64),
+                          (1 << 20, 0, 64), (50000, 0, 8), (50000, 8, 24), (300000, 0, 40), (8191, 16, 64)):
+        keys = rng.integers(0, 1 << 63, size=count, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=count, dtype=np.uint64)
+        if count % 2 == 1:
+            keys &= np.uint64(0x00FF00FF00FF00FF)  # many duplicates: stability matters
+        vals = np.arange(count, dtype=np.uint32)
+        k2, v2 = ctx.dbg_sort_pairs(keys, vals, lo, hi)
+        mask = np.uint64(((1 << hi) - 1) ^ ((1 << lo) - 1)) if hi < 64 else np.uint64(~((1 << lo) - 1) & 0xFFFFFFFFFFFFFFFF)
+        order = np.argsort(keys & mask, kind="stable")
+        assert first_diff(v2, vals[order]) is None, (count, lo, hi, first_diff(v2, vals[order]))
+        assert first_diff(k2, keys[order]) is None, (count, lo, hi)
+
+
+def test_known_answers_saca_rs_411(ctx, vectors):
+    # /root/reference/src/saca.rs:409-413 `detailed`, through the GPU path
+    for v in vectors["reference"]["saca_rs_411_412"]:
+        t = v["input"].encode()
+        assert list(ctx.suffix_array(t)) == v["sa"]
+        bwt, origin = ctx.bwt_forward(t)
+        assert bwt.tobytes() == v["bwt"].encode() and origin == v["origin"]
+        assert ctx.bwt_inverse(bwt, origin).tobytes() == t
+
+
+def test_golden_vectors(ctx, vectors, license_bytes):
+    for name, data in (("abracababra", b"abracababra"), ("LICENSE", license_bytes)):
+        g = vectors["oracle"][name]
+        assert list(ctx.suffix_array(data)) == g["sa"]
+        bwt, origin = ctx.bwt_forward(data)
+        assert bwt.tobytes().hex() == g["bwt_hex"] and origin == g["origin"]
+        dc = ctx.dc_encode(bwt)
+        assert list(dc["init"]) == g["dc_init"] and list(dc["d"]) == g["dc_d"]
+        assert dc["sym"].tobytes().hex() == g["dc_sym_hex"] and dc["rank"].tobytes().hex() == g["dc_rank_hex"]
+        assert ctx.block_encode("rawdc", data).hex() == g["rawdc_records_hex"]
+        for m in MODELS:
+            s = ctx.block_encode(m, data)
+            assert s.hex() == g["streams_hex"][m]
+            assert ctx.block_decode(m, s, len(data)) == data  # src/block/dc.rs:187-192 roundtrips
+
+
+def check_all_stages(ctx, orc, t, models=("dark",), naive=False):
+    n = len(t)
+    want_sa = orc.sa_naive(t) if (naive or n == 1) else orc.sa_sais(t)
+    got_sa = ctx.suffix_array(t)
+    assert first_diff(got_sa, want_sa) is None, ("sa", n, first_diff(got_sa, want_sa))
+    want_bwt, want_origin = orc.bwt_forward(t, want_sa)
+    bwt, origin = ctx.bwt_forward(t)
+    assert origin == want_origin and first_diff(bwt, want_bwt) is None, ("bwt", n, origin, want_origin)
+    back = ctx.bwt_inverse(bwt, origin)
+    assert first_diff(back, t) is None, ("ibwt", n, first_diff(back, t))
+    want = orc.dc_encode(want_bwt)
+    got = ctx.dc_encode(bwt)
+    for key in ("init", "d", "sym", "rank"):
+        assert first_diff(got[key], want[key]) is None, ("dc." + key, n, first_diff(got[key], want[key]))
+    for m in models:
+        s = ctx.block_encode(m, t)
+        assert s == orc.block_dc_encode_bwt(m, want_bwt, want_origin), ("stream", m, n)
+        if not (t == 255).any():
+            assert ctx.block_decode(m, s, n) == t.tobytes(), ("decode", m, n)
+
+
+def test_seeded_small_inputs(ctx, orc):
+    for t in seeded_inputs(seed=41, count=50):
+        check_all_stages(ctx, orc, t, models=MODELS, naive=len(t) < 600)
+
+
+def test_structured_inputs(ctx, orc):
+    rng = np.random.default_rng(43)
+    cases = [
+        text_like(rng, 300000),
+        rng.choice(np.frombuffer(b"ACGT", np.uint8), size=262144 + 77),          # small-alphabet packing (32 symbols / key)
+        rng.integers(0, 256, size=200001, dtype=np.uint8),                         # random bytes incl. 0xFF
+        np.frombuffer(b"ab" * 70000, np.uint8),                                    # period 2: log n rounds, all active
+        np.zeros(100000, np.uint8),                                                # one symbol
+        np.concatenate([np.zeros(5000, np.uint8), np.ones(5000, np.uint8)] * 7),   # long runs
+        np.frombuffer(bytes(range(256)) * 300, np.uint8),                          # period 256
+        rng.integers(0, 2, size=150000, dtype=np.uint8),                           # binary alphabet (64 symbols / key)
+    ]
+    seg = text_like(rng, 9000)
+    cases.append(np.concatenate([text_like(rng, 50000), seg, text_like(rng, 30000), seg, seg, text_like(rng, 1000)]))
+    for t in cases:
+        check_all_stages(ctx, orc, np.ascontiguousarray(t), models=("dark",))
+
+
+def test_megabyte_text(ctx, orc):
+    rng = np.random.default_rng(47)
+    t = text_like(rng, 4 << 20, vocab=20000)
+    check_all_stages(ctx, orc, t, models=("dark", "ybs"))
+
+
+def test_tile_boundaries(ctx, orc):
+    # sizes around the kernels' tile sizes (2048 / 4096 slots) and a BWT whose runs straddle DC tiles
+    rng = np.random.default_rng(53)
+    for n in (2047, 2048, 2049, 4095, 4096, 4097, 8191, 8192, 8193, 12288, 65536 + 1):
+        t = rng.integers(0, 3, size=n, dtype=np.uint8)
+        check_all_stages(ctx, orc, t)
+    for n in (4096, 8192, 20000):
+        for bwt in (np.repeat(rng.integers(0, 5, size=n // 512 + 1, dtype=np.uint8), 512)[:n],
+                    rng.integers(0, 200, size=n, dtype=np.uint8)):
+            bwt = np.ascontiguousarray(bwt)
+            want = orc.dc_encode(bwt)
+            got = ctx.dc_encode(bwt)
+            for key in ("init", "d", "sym", "rank"):
+                assert first_diff(got[key], want[key]) is None, ("dc." + key, n, first_diff(got[key], want[key]))
+
+
+def test_errors_and_limits(ctx):
+    with pytest.raises(dark_amd.DarkError) as e:
+        ctx.suffix_array(b"")
+    assert e.value.code == dark_amd._lib.DK_E_ARG  # n == 0: the reference panics (src/saca.rs:107)
+    with pytest.raises(dark_amd.DarkError) as e:
+        ctx.suffix_array(np.zeros(CAP + 1, np.uint8))
+    assert e.value.code == dark_amd._lib.DK_E_ARG
+    with pytest.raises(dark_amd.DarkError) as e:
+        ctx.bwt_inverse(b"abc", 3)
+    assert e.value.code == dark_amd._lib.DK_E_ARG
+    with pytest.raises(dark_amd.DarkError) as e:
+        ctx.block_encode("nope", b"abc")
+    assert e.value.code == dark_amd._lib.DK_E_MODEL
+    s = ctx.block_encode("dark", b"hello\xffworld")  # encodes (bit-exact with the reference) ...
+    with pytest.raises(dark_amd.DarkError):           # ... but the format cannot carry symbol 0xFF back
+        ctx.block_decode("dark", s, 11)
+    assert ctx.block_decode("dark", ctx.block_encode("dark", b"aaaaaaa"), 7) == b"aaaaaaa"  # one-symbol quirk handled
+    assert list(ctx.suffix_array(b"z")) == [0]  # n == 1: reference asserts (saca.rs:300); the GPU path just answers
+
+
+def test_mirror_interfaces(vectors, license_bytes):
+    # the reference's own tests, written against the mirrored interface (src/saca.rs:393-407, src/block/dc.rs:176-192)
+    from dark_amd import block, saca
+    con = saca.Constructor(len(b"banana"))
+    assert con.capacity() == 6
+    assert list(con.compute(b"banana")) == [5, 3, 1, 0, 4, 2]
+    for m, data in (("exp", b"abracababra"), ("exp", license_bytes), ("ybs", license_bytes)):
+        enc = block.dc.Encoder(len(data), m)
+        stream = enc.encode(data)
+        dec = block.dc.Decoder(len(data), enc.model)
+        assert dec.decode(stream) == data
