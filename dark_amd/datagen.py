@@ -1,0 +1,70 @@
+"""Seeded synthetic blocks for the BASELINE.json configs: the real corpora (book1, enwik8, enwik9)
+are not in the image and there is no network, so every config has a deterministic stand-in of the same size and flavour."""
+import numpy as np
+
+ALPHA = 96  # printable bytes 32..127
+
+
+def _markov(n, seed, order, chains):
+    """order-k Markov text over 96 printable bytes, generated as `chains` independent chains advanced in lock-step
+    (vectorised over chains; every chain is a contiguous stretch of the output)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    nctx = ALPHA ** order
+    cand = rng.integers(0, ALPHA, size=(nctx, 4), dtype=np.uint8)  # four candidate successors per context
+    # make common contexts point at space / 'e' / 't' a bit more often: word-like structure
+    cand[rng.integers(0, nctx, size=nctx // 5), 0] = 0
+    steps = -(-n // chains)
+    state = rng.integers(0, nctx, size=chains, dtype=np.int64)
+    out = np.empty((steps, chains), dtype=np.uint8)
+    thresholds = np.array([141, 205, 238], dtype=np.uint8)  # P = .55 .25 .13 .07
+    for s in range(steps):
+        u = rng.integers(0, 256, size=chains, dtype=np.uint8)
+        choice = (u > thresholds[0]).astype(np.int64) + (u > thresholds[1]) + (u > thresholds[2])
+        sym = cand[state, choice]
+        out[s] = sym
+        state = (state * ALPHA + sym) % nctx
+    text = np.ascontiguousarray(out.T).reshape(-1)[:n]
+    text += 32
+    return text, rng
+
+
+def wiki_like(n, seed=2):
+    """config 2 / 4 stand-in for enwik8 / enwik9 blocks: order-3 Markov over 96 printable bytes, 5 % of the length
+    overwritten by repeated 256 B - 8 KiB segments (forces deep LCPs like wiki boilerplate)."""
+    chains = int(min(65536, max(1, n // 512)))
+    text, rng = _markov(n, seed, 3, chains)
+    budget = n // 20
+    while budget > 0 and n > 16384:
+        ln = int(rng.integers(256, 8193))
+        src = int(rng.integers(0, n - ln))
+        dst = int(rng.integers(0, n - ln))
+        text[dst:dst + ln] = text[src:src + ln].copy()
+        budget -= ln
+    return text
+
+
+def english_like(n=768771, seed=1):
+    """config 1 stand-in for Calgary book1: order-2 Markov English-like text"""
+    text, _ = _markov(n, seed, 2, int(min(4096, max(1, n // 256))))
+    return text
+
+
+def acgt(n=1 << 28, seed=3):
+    """config 3: i.i.d. uniform over {A,C,G,T}"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n, dtype=np.uint8)]
+
+
+def random_bytes(n=1 << 30, seed=50):
+    """config 5: i.i.d. uniform bytes (contains 0xFF: encodes, but the reference format cannot decode it)"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return rng.integers(0, 256, size=n, dtype=np.uint8)
+
+
+WORKLOADS = {
+    "book1_like_768771": lambda seed=1: english_like(768771, seed),
+    "enwik8_like_1e8": lambda seed=2: wiki_like(100_000_000, seed),
+    "acgt_2p28": lambda seed=3: acgt(1 << 28, seed),
+    "enwik9_block_125e6": lambda seed=40: wiki_like(125_000_000, seed),
+    "random_2p30": lambda seed=50: random_bytes(1 << 30, seed),
+}
