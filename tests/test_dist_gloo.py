@@ -1,0 +1,75 @@
+"""N>1 path on CPU: world_size-2 gloo run of bench.py's exchange step (lengths all_gather + padded gather of the final
+bitstreams to rank 0).  The per-rank streams come from the product's host entropy stage fed by oracle-made DC streams, so
+no GPU is needed; the collective pattern is the one bench.py uses with backend nccl (= RCCL) on the GPU box."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from dark_amd import datagen, model
+    from oracle import orc
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    # block b -> rank b (independent blocks, no data-path collective)
+    block = datagen.wiki_like(60000, seed=40 + rank)
+    bwt, origin = orc.bwt_forward(block)
+    dc = orc.dc_encode(bwt)
+    stream = np.frombuffer(model.stream_encode("dark", len(block), dc["init"], dc["d"], dc["sym"], origin), dtype=np.uint8)
+    # exchange step, as in bench.py gather_streams()
+    ln = torch.tensor([len(stream)], dtype=torch.int64)
+    lens = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(lens, ln)
+    mx = int(max(int(x.item()) for x in lens))
+    pad = torch.zeros(mx, dtype=torch.uint8)
+    pad[:len(stream)] = torch.from_numpy(stream.copy())
+    if rank == 0:
+        bufs = [torch.empty(mx, dtype=torch.uint8) for _ in range(world)]
+        dist.gather(pad, bufs, dst=0)
+        got = [b[:int(l.item())].numpy().tobytes() for b, l in zip(bufs, lens)]
+        # rank 0 checks every gathered stream decodes to the block its owner compressed
+        ok = True
+        for r, s in enumerate(got):
+            blk = datagen.wiki_like(60000, seed=40 + r)
+            ok = ok and orc.block_dc_decode("dark", s, len(blk)) == blk.tobytes()
+            ok = ok and s == orc.block_dc_encode("dark", blk)
+        q.put(("rank0", ok, [len(s) for s in got]))
+    else:
+        dist.gather(pad, None, dst=0)
+        q.put(("rank%d" % rank, True, [len(stream)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_block_parallel_gather():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    by = {r[0]: r for r in results}
+    assert by["rank0"][1] is True
+    assert len(by["rank0"][2]) == 2 and by["rank0"][2][1] == by["rank1"][2][0]
