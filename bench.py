@@ -135,6 +135,7 @@ def main():
     # decode leg (same protocol, reported beside the headline)
     decode_mbps = None
     roundtrip_ok = None
+    dstats = None
     if not args.no_decode:
         d_out = torch.empty(n, dtype=torch.uint8, device=dev)
         try:

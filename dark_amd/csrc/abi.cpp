@@ -160,6 +160,7 @@ int dk_ctx_create(int hip_device, size_t max_n, dk_ctx **out) {
     ok = ok && hipMalloc(reinterpret_cast<void **>(&c->ws), c->ws_size) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void **>(&c->d_mail), 1024 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&c->h_mail), 1024 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMemset(c->d_mail, 0, 1024 * sizeof(uint32_t)) == hipSuccess;
     if (!ok) {
         dk_ctx_destroy(c);
         return DK_E_NOMEM;
@@ -438,6 +439,7 @@ int dk_dbg_sort_pairs(dk_ctx *ctx, uint64_t *keys, uint32_t *vals, size_t count,
     DK_HIP(ctx, hipMemcpyAsync(k0, keys, count * 8, hipMemcpyHostToDevice, ctx->stream));
     DK_HIP(ctx, hipMemcpyAsync(v0, vals, count * 4, hipMemcpyHostToDevice, ctx->stream));
     DK_TRY(sort_pairs(ctx, k0, k1, v0, v1, count, begin_bit, end_bit));
+    DK_TRY(sort_check_error(ctx));
     DK_HIP(ctx, hipMemcpyAsync(keys, k0, count * 8, hipMemcpyDeviceToHost, ctx->stream));
     DK_HIP(ctx, hipMemcpyAsync(vals, v0, count * 4, hipMemcpyDeviceToHost, ctx->stream));
     DK_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -2,13 +2,19 @@
 // It takes the place of all the sorting work inside saca() (src/saca.rs:270-340): bucket placement, the induced
 // sorts and the naming pass become "sort by packed prefix, then by (group, rank of the suffix h further on)".
 //
-// Per pass (v1, three phases, no inter-workgroup spinning):
-//   k_radix_hist     one tile (4096 pairs) per workgroup -> 256-bin histogram in LDS -> tile_hist[tile][256]
-//   k_radix_scan_*   digit-major exclusive scan of tile_hist (chunk sums / chunk scan / apply), rows stay coalesced
-//   k_radix_scatter  re-reads the tile, ranks keys stably with wave64 ballots (match-any over the 8 digit bits),
-//                    reorders the tile in LDS so that equal digits are contiguous, then writes runs to HBM
-// Algorithmic bytes per pass: hist 8 B/key read; scatter 12 B/pair read + 12 B/pair written.
+// Single-pass-per-digit path (default, count < 2^30):
+//   k_radix_hist_all one read of the keys -> the 256-bin histograms of ALL passes (LDS atomics) -> digit_base[pass][256]
+//   k_radix_scatter<true>  per pass: tiles are handed out by an atomic ticket, each tile ranks its keys stably with wave64
+//                    ballots (match-any over the 8 digit bits), publishes its per-digit counts as {flag,value} words and
+//                    finds its global offsets by decoupled look-back over the preceding tiles' words (relaxed agent-scope
+//                    atomics; the word IS the flag, so no fence is needed), reorders the tile in LDS so that equal digits
+//                    are contiguous, then writes runs to HBM.  Every spin is bounded and sets an error word.
+// Three-phase path (count >= 2^30, or DK_SORT=classic): k_radix_hist per pass -> k_radix_scan_{a,b,c} -> k_radix_scatter<false>.
+// Algorithmic bytes per pass: scatter 12 B/pair read + 12 B/pair written; hist_all 8 B/key once per sort.
 #include "context.hpp"
+#include <cstdlib>
+#include <string>
+
 #include "device_util.hpp"
 
 namespace dk {
@@ -50,20 +56,36 @@ __global__ __launch_bounds__(256) void k_radix_scan_a(const uint32_t *__restrict
     for (size_t t = t0; t < t1; ++t) s += tile_hist[t * 256 + d];
     chunk_sum[g * 256 + d] = s;
 }
-// phase B (one workgroup): digit-major exclusive scan of the chunk sums
-__global__ __launch_bounds__(256) void k_radix_scan_b(uint32_t *__restrict__ chunk_sum, size_t nchunks) {
-    __shared__ uint32_t s_tmp[RS_WAVES + 1];
-    const int d = threadIdx.x;
+// phase B (one workgroup of 1024): digit-major exclusive scan of the chunk sums; 4 threads share a digit's column
+__global__ __launch_bounds__(1024) void k_radix_scan_b(uint32_t *__restrict__ chunk_sum, size_t nchunks) {
+    __shared__ uint32_t s_tmp[16 + 1];
+    __shared__ uint32_t s_part[4][256];
+    const int d = threadIdx.x & 255, part = threadIdx.x >> 8;
+    const size_t q = (nchunks + 3) / 4;
+    const size_t g0 = part * q, g1 = g0 + q < nchunks ? g0 + q : nchunks;
     uint32_t run = 0;
 #pragma unroll 8
-    for (size_t g = 0; g < nchunks; ++g) {
+    for (size_t g = g0; g < g1; ++g) {
         const uint32_t v = chunk_sum[g * 256 + d];
         chunk_sum[g * 256 + d] = run;
         run += v;
     }
-    const uint32_t base = block_excl_sum<RS_WAVES>(run, s_tmp, nullptr);
+    s_part[part][d] = run;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t t = s_part[p][d];
+        if (p < part) before += t;
+        total += t;
+    }
+    // exclusive scan of the digit totals over d: only the part-0 threads carry a value
+    const uint32_t base = block_excl_sum<16>(part == 0 ? total : 0u, s_tmp, nullptr);
+    if (part == 0) s_part[0][d] = base;
+    __syncthreads();
+    const uint32_t off = s_part[0][d] + before;
 #pragma unroll 8
-    for (size_t g = 0; g < nchunks; ++g) chunk_sum[g * 256 + d] += base;
+    for (size_t g = g0; g < g1; ++g) chunk_sum[g * 256 + d] += off;
 }
 // phase C: tile counts -> exclusive global offsets
 __global__ __launch_bounds__(256) void k_radix_scan_c(uint32_t *__restrict__ tile_hist, size_t ntiles, size_t tiles_per_chunk,
@@ -80,20 +102,74 @@ __global__ __launch_bounds__(256) void k_radix_scan_c(uint32_t *__restrict__ til
     }
 }
 
+// histograms of every pass in one read of the keys
+__global__ __launch_bounds__(RS_BLOCK) void k_radix_hist_all(const uint64_t *__restrict__ keys, size_t n, int begin_bit, int npasses,
+                                                              uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[8 * 256];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < npasses * 256; i += RS_BLOCK) h[i] = 0;
+    __syncthreads();
+    const size_t stride = static_cast<size_t>(gridDim.x) * RS_BLOCK;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * RS_BLOCK + tid; i < n; i += stride) {
+        const uint64_t k = keys[i] >> begin_bit;
+        for (int p = 0; p < npasses; ++p) atomicAdd(&h[p * 256 + (static_cast<uint32_t>(k >> (8 * p)) & 0xFFu)], 1u);
+    }
+    __syncthreads();
+    for (int i = tid; i < npasses * 256; i += RS_BLOCK)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+// one workgroup per pass: counts -> exclusive digit starts
+__global__ __launch_bounds__(256) void k_radix_base_scan(uint32_t *__restrict__ hist) {
+    __shared__ uint32_t s_tmp[RS_WAVES + 1];
+    uint32_t *row = hist + static_cast<size_t>(blockIdx.x) * 256;
+    const uint32_t v = row[threadIdx.x];
+    row[threadIdx.x] = block_excl_sum<RS_WAVES>(v, s_tmp, nullptr);
+}
+
+__global__ void k_radix_fold_err(const uint32_t *__restrict__ err, uint32_t *__restrict__ acc) {
+    if (*err) *acc = 1;
+}
+
+constexpr uint32_t ST_LOCAL = 1u << 30, ST_INCL = 2u << 30, ST_MASK = (1u << 30) - 1;
+constexpr uint32_t RS_SPIN_LIMIT = 1u << 22;
+
+// LOOKBACK = false: tile = blockIdx.x, offsets come from the scanned tile_offs table.
+// LOOKBACK = true : tile = atomic ticket, `tile_offs` is the status array [ntiles][256] (zeroed), `digit_base` the
+//                   exclusive digit starts of this pass, ctrl[0] the ticket counter, ctrl[1] the error word.
+template <bool LOOKBACK>
 __global__ __launch_bounds__(RS_BLOCK) void k_radix_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                              uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n,
-                                                             int shift, const uint32_t *__restrict__ tile_offs) {
+                                                             int shift, uint32_t *__restrict__ tile_offs,
+                                                             const uint32_t *__restrict__ digit_base, uint32_t *__restrict__ ctrl,
+                                                             uint32_t xcd_tiles) {
     __shared__ uint64_t s_keys[RS_TILE];          // 32 KiB: tile of keys in digit order; reused for the values
     __shared__ uint32_t s_cnt[RS_WAVES][256];     // per-wave digit counters, then exclusive over waves
     __shared__ uint32_t s_start[256];             // tile-local start of each digit
     __shared__ uint32_t s_gbase[256];             // global offset of the digit minus its tile-local start
     __shared__ uint32_t s_tmp[RS_WAVES + 1];
+    __shared__ uint32_t s_ticket;
+    __shared__ uint32_t s_hist[256];              // LOOKBACK: tile histogram made before the ranking, published early
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t tile_base = static_cast<size_t>(blockIdx.x) * RS_TILE;
+    uint32_t tile = blockIdx.x;
+    if (!LOOKBACK && xcd_tiles) {
+        // XCD-aware order: blocks b and b+8 share an XCD (round-robin dispatch, speed only); give every XCD one contiguous
+        // range of tiles so that neighbouring output runs meet in the same L2.  Grid = 8 * ceil(ntiles / 8).
+        const uint32_t per = gridDim.x / 8;
+        tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+        if (tile >= xcd_tiles) return;
+    }
+    if (LOOKBACK) {  // tickets: a tile only ever waits for tiles that already started
+        if (tid == 0) s_ticket = atomicAdd(&ctrl[0], 1u);
+        __syncthreads();
+        tile = s_ticket;
+    }
+    const size_t tile_base = static_cast<size_t>(tile) * RS_TILE;
     const size_t left = n - tile_base;
     const uint32_t valid = left < static_cast<size_t>(RS_TILE) ? static_cast<uint32_t>(left) : RS_TILE;
 
     for (int i = tid; i < RS_WAVES * 256; i += RS_BLOCK) (&s_cnt[0][0])[i] = 0;
+    if (LOOKBACK) s_hist[tid] = 0;
+    __syncthreads();
 
     // wave w owns pairs [w*1024, (w+1)*1024) of the tile, lane-striped so that loads coalesce
     uint64_t key[RS_KPT];
@@ -105,12 +181,20 @@ __global__ __launch_bounds__(RS_BLOCK) void k_radix_scatter(const uint64_t *__re
         if (li < valid) {
             key[k] = kin[tile_base + li];
             val[k] = vin[tile_base + li];
+            if (LOOKBACK) atomicAdd(&s_hist[digit_of(key[k], shift)], 1u);
         } else {
             key[k] = ~0ull;  // padding sorts behind every real pair of the tile and is never written
             val[k] = 0;
         }
     }
     __syncthreads();
+    uint32_t *mine = nullptr;
+    uint32_t my_cnt = 0;
+    if (LOOKBACK) {  // publish this tile's counts before the (long) ranking so that successors rarely wait
+        my_cnt = s_hist[tid];
+        mine = tile_offs + static_cast<size_t>(tile) * 256 + tid;
+        __hip_atomic_store(mine, (tile == 0 ? ST_INCL : ST_LOCAL) | my_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     // stable rank inside the wave: lanes holding the same digit find each other with 8 ballots
     uint32_t rnk[RS_KPT];
@@ -143,9 +227,34 @@ __global__ __launch_bounds__(RS_BLOCK) void k_radix_scatter(const uint64_t *__re
             s_cnt[w][d] = run;
             run += c;
         }
+        uint32_t goff;
+        if (LOOKBACK) {
+            // (padding keys of the last tile were never counted in s_hist: they are not real pairs)
+            const uint32_t cnt = my_cnt;
+            uint32_t excl = 0;
+            if (tile != 0) {
+                const uint32_t *look = mine - 256;
+                uint32_t spins = 0;
+                for (;;) {
+                    const uint32_t v = __hip_atomic_load(look, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((v >> 30) == 0) {  // predecessor has not published yet
+                        if (++spins > RS_SPIN_LIMIT) { ctrl[1] = 1; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        continue;
+                    }
+                    excl += v & ST_MASK;
+                    if (v & ST_INCL) break;
+                    look -= 256;
+                }
+                __hip_atomic_store(mine, ST_INCL | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            goff = digit_base[d] + excl;
+        } else {
+            goff = tile_offs[static_cast<size_t>(tile) * 256 + d];
+        }
         const uint32_t start = block_excl_sum<RS_WAVES>(run, s_tmp, nullptr);
         s_start[d] = start;
-        s_gbase[d] = tile_offs[static_cast<size_t>(blockIdx.x) * 256 + d] - start;
+        s_gbase[d] = goff - start;
     }
     __syncthreads();
 
@@ -182,10 +291,8 @@ __global__ __launch_bounds__(RS_BLOCK) void k_radix_scatter(const uint64_t *__re
 
 // Sorts `count` pairs on key bits [begin_bit, end_bit).  keys/vals are the input buffers, *_alt equally sized scratch;
 // on return `keys` and `vals` refer to whichever buffer holds the sorted data (the references are swapped per pass).
-int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
-               int begin_bit, int end_bit) {
-    if (count <= 1 || end_bit <= begin_bit) return DK_OK;
-    if (count > 0xFFFFFFFEull) return ctx->fail(DK_E_ARG, "sort_pairs: count too large");
+static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
+                              int begin_bit, int end_bit) {
     const size_t ntiles = div_up(count, RS_TILE);
     const size_t tiles_per_chunk = div_up(ntiles, RS_MAX_CHUNKS);
     const size_t nchunks = div_up(ntiles, tiles_per_chunk);
@@ -202,12 +309,15 @@ int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&val
         {
             LaunchScope ls(ctx, K_RADIX_SCAN, 3.0 * 1024.0 * ntiles);
             k_radix_scan_a<<<dim3(nchunks), dim3(256), 0, st>>>(tile_hist, ntiles, tiles_per_chunk, chunk_sum);
-            k_radix_scan_b<<<dim3(1), dim3(256), 0, st>>>(chunk_sum, nchunks);
+            k_radix_scan_b<<<dim3(1), dim3(1024), 0, st>>>(chunk_sum, nchunks);
             k_radix_scan_c<<<dim3(nchunks), dim3(256), 0, st>>>(tile_hist, ntiles, tiles_per_chunk, chunk_sum);
         }
         {
             LaunchScope ls(ctx, K_RADIX_SCATTER, 24.0 * count);
-            k_radix_scatter<<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(keys, vals, keys_alt, vals_alt, count, shift, tile_hist);
+            static const bool xcd = [] { const char *e = getenv("DK_XCD"); return !(e && e[0] == '0'); }();
+            const size_t grid = xcd ? 8 * div_up(ntiles, 8) : ntiles;
+            k_radix_scatter<false><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(keys, vals, keys_alt, vals_alt, count, shift, tile_hist,
+                                                                         nullptr, nullptr, xcd ? static_cast<uint32_t>(ntiles) : 0u);
         }
         DK_HIP(ctx, hipGetLastError());
         std::swap(keys, keys_alt);
@@ -216,6 +326,64 @@ int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&val
         ctx->stats.sorted_elements += count;
     }
     ctx->ws_release(mark);
+    return DK_OK;
+}
+
+static int sort_pairs_onesweep(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
+                               int begin_bit, int end_bit) {
+    const size_t ntiles = div_up(count, RS_TILE);
+    const int npasses = (end_bit - begin_bit + 7) / 8;
+    const size_t mark = ctx->ws_mark();
+    // ctrl words (ticket, error) sit in front of the status rows so that one memset clears both
+    uint32_t *digit_base = ctx->ws_alloc<uint32_t>(static_cast<size_t>(npasses) * 256);
+    uint32_t *ctrl = ctx->ws_alloc<uint32_t>(64 + ntiles * 256);
+    if (!digit_base || !ctrl) return DK_E_NOMEM;
+    uint32_t *status = ctrl + 64;
+    uint32_t *d_err = ctx->d_mail + 12;
+    hipStream_t st = ctx->stream;
+    DK_HIP(ctx, hipMemsetAsync(digit_base, 0, static_cast<size_t>(npasses) * 256 * sizeof(uint32_t), st));
+    {
+        LaunchScope ls(ctx, K_RADIX_HIST, 8.0 * count);
+        const size_t blocks = std::min<size_t>(div_up(count, RS_BLOCK * 8), 2048);
+        k_radix_hist_all<<<dim3(blocks), dim3(RS_BLOCK), 0, st>>>(keys, count, begin_bit, npasses, digit_base);
+        k_radix_base_scan<<<dim3(npasses), dim3(256), 0, st>>>(digit_base);
+    }
+    for (int p = 0; p < npasses; ++p) {
+        DK_HIP(ctx, hipMemsetAsync(ctrl, 0, (64 + ntiles * 256) * sizeof(uint32_t), st));
+        {
+            LaunchScope ls(ctx, K_RADIX_SCATTER, 24.0 * count);
+            k_radix_scatter<true><<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(keys, vals, keys_alt, vals_alt, count, begin_bit + 8 * p,
+                                                                          status, digit_base + p * 256, ctrl, 0u);
+        }
+        DK_HIP(ctx, hipGetLastError());
+        // fold the error word of this pass into the mailbox (checked once per suffix sort / debug call)
+        k_radix_fold_err<<<dim3(1), dim3(1), 0, st>>>(ctrl + 1, d_err);
+        std::swap(keys, keys_alt);
+        std::swap(vals, vals_alt);
+        ctx->stats.sort_passes += 1;
+        ctx->stats.sorted_elements += count;
+    }
+    ctx->ws_release(mark);
+    return DK_OK;
+}
+
+int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
+               int begin_bit, int end_bit) {
+    if (count <= 1 || end_bit <= begin_bit) return DK_OK;
+    if (count > 0xFFFFFFFEull) return ctx->fail(DK_E_ARG, "sort_pairs: count too large");
+    // default: three-phase passes with the XCD-aware tile order (measured 4.2 TB/s on the scatter); DK_SORT=onesweep selects the
+    // single-kernel look-back variant (no per-pass histogram, but ticket order defeats the XCD locality: 2.2 TB/s)
+    static const bool onesweep = [] { const char *e = getenv("DK_SORT"); return e && std::string(e) == "onesweep"; }();
+    if (!onesweep || count >= (1ull << 30)) return sort_pairs_classic(ctx, keys, keys_alt, vals, vals_alt, count, begin_bit, end_bit);
+    return sort_pairs_onesweep(ctx, keys, keys_alt, vals, vals_alt, count, begin_bit, end_bit);
+}
+
+// error word of the look-back path (non-zero: a spin hit its bound); resets it
+int sort_check_error(dk_ctx *ctx) {
+    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 12, ctx->d_mail + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    DK_HIP(ctx, hipMemsetAsync(ctx->d_mail + 12, 0, sizeof(uint32_t), ctx->stream));
+    DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_mail[12]) return ctx->fail(DK_E_INTERNAL, "radix sort: decoupled look-back timed out");
     return DK_OK;
 }
 

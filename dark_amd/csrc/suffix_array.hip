@@ -10,6 +10,8 @@
 //   5. while active:     key = (group id, rank2) with rank2 = rank[i+h]+h, or n-1-i for i+h >= n (shorter is smaller);
 //                        sort_pairs on exactly the bits in use; rerank; h *= 2
 // Only members of unresolved groups are ever sorted again (Larsson-Sadakane style filtering).
+#include <cstdlib>
+
 #include "context.hpp"
 #include "device_util.hpp"
 
@@ -58,8 +60,10 @@ struct RerankAgg { uint32_t surv, heads, last_head, pad; };
 
 // flags of the RR_IPT slots starting at a0: head[j] = key differs from its predecessor (slot 0 is a head);
 // surv[j] = the slot's group has more than one member
-__device__ __forceinline__ void slot_flags(const uint64_t *__restrict__ keys, size_t count, size_t a0, bool head[RR_IPT],
-                                           bool surv[RR_IPT]) {
+// oldh[j] = the slot is a head AND was already the head of its group before this round (gshift >= 0: the group id sits
+// above bit gshift of the key): members of such a new group keep their rank, so the rank scatter can be skipped.
+__device__ __forceinline__ void slot_flags(const uint64_t *__restrict__ keys, size_t count, size_t a0, int gshift, bool head[RR_IPT],
+                                           bool surv[RR_IPT], bool oldh[RR_IPT]) {
     uint64_t k[RR_IPT + 2];
 #pragma unroll
     for (int j = 0; j < RR_IPT + 2; ++j) {
@@ -70,6 +74,7 @@ __device__ __forceinline__ void slot_flags(const uint64_t *__restrict__ keys, si
     for (int j = 0; j < RR_IPT; ++j) {
         const size_t a = a0 + j;
         head[j] = a < count && (a == 0 || k[j + 1] != k[j]);
+        oldh[j] = head[j] && gshift >= 0 && (a == 0 || (k[j + 1] >> gshift) != (k[j] >> gshift));
     }
 #pragma unroll
     for (int j = 0; j < RR_IPT; ++j) {
@@ -79,18 +84,19 @@ __device__ __forceinline__ void slot_flags(const uint64_t *__restrict__ keys, si
     }
 }
 
-__global__ __launch_bounds__(RR_BLOCK) void k_rerank_reduce(const uint64_t *__restrict__ keys, size_t count,
+// last_head values travel as (slot << 1) | old_head so that one max-scan carries both
+__global__ __launch_bounds__(RR_BLOCK) void k_rerank_reduce(const uint64_t *__restrict__ keys, size_t count, int gshift,
                                                              RerankAgg *__restrict__ agg) {
     __shared__ uint32_t s_red[3][RR_WAVES];
     const size_t a0 = static_cast<size_t>(blockIdx.x) * RR_TILE + static_cast<size_t>(threadIdx.x) * RR_IPT;
-    bool head[RR_IPT], surv[RR_IPT];
-    slot_flags(keys, count, a0, head, surv);
+    bool head[RR_IPT], surv[RR_IPT], oldh[RR_IPT];
+    slot_flags(keys, count, a0, gshift, head, surv, oldh);
     uint32_t ns = 0, nh = 0, lh = 0;
 #pragma unroll
     for (int j = 0; j < RR_IPT; ++j) {
         ns += surv[j];
         nh += head[j] && surv[j];
-        if (head[j]) lh = static_cast<uint32_t>(a0 + j);
+        if (head[j]) lh = (static_cast<uint32_t>(a0 + j) << 1) | (oldh[j] ? 1u : 0u);
     }
     ns = wave_sum(ns);
     nh = wave_sum(nh);
@@ -139,20 +145,20 @@ __global__ __launch_bounds__(1024) void k_rerank_scan(RerankAgg *__restrict__ ag
 
 // pos_in == nullptr means slot a sits at SA position a (first rerank, straight after the initial sort)
 __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx,
-                                                            const uint32_t *__restrict__ pos_in, size_t count,
+                                                            const uint32_t *__restrict__ pos_in, size_t count, int gshift,
                                                             const RerankAgg *__restrict__ agg, uint32_t *__restrict__ rank,
                                                             uint32_t *__restrict__ sa, uint32_t *__restrict__ out_idx,
                                                             uint32_t *__restrict__ out_pos, uint32_t *__restrict__ out_gid) {
     __shared__ uint32_t s_tmp[RR_WAVES + 1];
     const size_t a0 = static_cast<size_t>(blockIdx.x) * RR_TILE + static_cast<size_t>(threadIdx.x) * RR_IPT;
-    bool head[RR_IPT], surv[RR_IPT];
-    slot_flags(keys, count, a0, head, surv);
+    bool head[RR_IPT], surv[RR_IPT], oldh[RR_IPT];
+    slot_flags(keys, count, a0, gshift, head, surv, oldh);
     uint32_t ns = 0, nh = 0, lh = 0;
 #pragma unroll
     for (int j = 0; j < RR_IPT; ++j) {
         ns += surv[j];
         nh += head[j] && surv[j];
-        if (head[j]) lh = static_cast<uint32_t>(a0 + j);
+        if (head[j]) lh = (static_cast<uint32_t>(a0 + j) << 1) | (oldh[j] ? 1u : 0u);
     }
     const RerankAgg base = agg[blockIdx.x];
     uint32_t es = base.surv + block_excl_sum<RR_WAVES>(ns, s_tmp, nullptr);
@@ -163,11 +169,11 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
     for (int j = 0; j < RR_IPT; ++j) {
         const size_t a = a0 + j;
         if (a >= count) break;
-        if (head[j]) el = static_cast<uint32_t>(a);
+        if (head[j]) el = (static_cast<uint32_t>(a) << 1) | (oldh[j] ? 1u : 0u);
         const uint32_t suffix = idx[a];
         const uint32_t my_pos = pos_in ? pos_in[a] : static_cast<uint32_t>(a);
-        const uint32_t head_pos = pos_in ? pos_in[el] : el;
-        rank[suffix] = head_pos;
+        // members of a new group whose head already headed the old group keep their rank: no scatter
+        if (!(el & 1u)) rank[suffix] = pos_in ? pos_in[el >> 1] : (el >> 1);
         if (!surv[j]) {
             sa[my_pos] = suffix;  // the group is a singleton: this suffix is in its final place
         } else {
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256) void k_build_keys(const uint32_t *__restrict__
     keys[a] = (static_cast<uint64_t>(act_gid[a]) << kbits) | r2;
 }
 
-int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_t *pos_in, size_t count, uint32_t *rank,
+int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_t *pos_in, size_t count, int gshift, uint32_t *rank,
            uint32_t *sa, uint32_t *out_idx, uint32_t *out_pos, uint32_t *out_gid, size_t *active, size_t *groups) {
     const size_t ntiles = div_up(count, RR_TILE);
     const size_t mark = ctx->ws_mark();
@@ -201,7 +207,7 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
     hipStream_t st = ctx->stream;
     {
         LaunchScope ls(ctx, K_RERANK_REDUCE, 8.0 * count);
-        k_rerank_reduce<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, count, agg);
+        k_rerank_reduce<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, count, gshift, agg);
     }
     {
         LaunchScope ls(ctx, K_RERANK_SCAN, 32.0 * ntiles);
@@ -209,7 +215,7 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
     }
     {
         LaunchScope ls(ctx, K_RERANK_APPLY, 8.0 * count + 4.0 * count + 4.0 * count + 12.0 * count);
-        k_rerank_apply<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, agg, rank, sa, out_idx, out_pos, out_gid);
+        k_rerank_apply<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gshift, agg, rank, sa, out_idx, out_pos, out_gid);
     }
     DK_HIP(ctx, hipGetLastError());
     DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -273,11 +279,13 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
 
     // 4. first rerank (slots are SA positions)
     size_t active = 0, groups = 0;
-    DK_TRY(rerank(ctx, keys, vals, nullptr, n, rank, d_sa, vals_alt, pos, gid, &active, &groups));
+    DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, rank, d_sa, vals_alt, pos, gid, &active, &groups));
     std::swap(vals, vals_alt);  // vals = suffix indices of the active list
 
     // 5. doubling rounds
     uint64_t h = static_cast<uint64_t>(spk);
+    static const bool trace = getenv("DK_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[dk] n=%zu sigma=%u bits=%d spk=%d: after init sort active=%zu groups=%zu\n", n, sigma, bits, spk, active, groups);
     while (active > 0) {
         if (ctx->stats.rounds > 40) return ctx->fail(DK_E_INTERNAL, "suffix_array: no convergence after 40 rounds");
         const uint32_t h_eff = static_cast<uint32_t>(std::min<uint64_t>(h, n));
@@ -291,16 +299,18 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
         DK_HIP(ctx, hipGetLastError());
         DK_TRY(sort_pairs(ctx, keys, keys_alt, vals, vals_alt, active, 0, kbits + gbits));
         size_t next_active = 0, next_groups = 0;
-        DK_TRY(rerank(ctx, keys, vals, pos, active, rank, d_sa, vals_alt, pos_alt, gid_alt, &next_active, &next_groups));
+        DK_TRY(rerank(ctx, keys, vals, pos, active, kbits, rank, d_sa, vals_alt, pos_alt, gid_alt, &next_active, &next_groups));
         std::swap(vals, vals_alt);
         std::swap(pos, pos_alt);
         std::swap(gid, gid_alt);
+        if (trace) fprintf(stderr, "[dk] round %u h=%llu sorted=%zu bits=%d -> active=%zu groups=%zu\n", ctx->stats.rounds, (unsigned long long)h, active, kbits + gbits, next_active, next_groups);
         active = next_active;
         groups = next_groups;
         ctx->stats.rounds += 1;
         h *= 2;
     }
     ctx->ws_release(mark);
+    DK_TRY(sort_check_error(ctx));
     return DK_OK;
 }
 
