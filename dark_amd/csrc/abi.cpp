@@ -26,8 +26,8 @@ int check_n(dk_ctx *ctx, size_t n) {
     return DK_OK;
 }
 size_t workspace_bytes(size_t max_n) {
-    // text copy n + bwt n + DC arrays 10 n + SA 4 n + suffix-sort temporaries 44 n + per-tile tables (< n) + slack
-    return 64 * max_n + (48u << 20);
+    // text copy n + bwt n + DC arrays 10 n + SA 4 n + suffix-sort temporaries 64 n + per-tile tables (< n) + slack
+    return 84 * max_n + (48u << 20);
 }
 struct ScopedCall {
     dk_ctx *c;

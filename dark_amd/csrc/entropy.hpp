@@ -92,19 +92,22 @@ private:
 class Decoder {
 public:
     Decoder(const uint8_t *in, size_t len) : in_(in), len_(len) {}
-    // offset of the code under `total`; the caller finds the symbol and then calls take()
-    inline uint32_t peek(uint32_t total) {
+    // The reference computes offset = (code - low) / r and searches the model for it.  floor(x / r) >= c  <=>  x >= c * r, so the
+    // search can compare x = code - low with border * r instead: same symbol, no second division.
+    inline void begin(uint32_t total) {
         feed();
         r_ = (rs_.hi - rs_.low) / total;
-        if (r_ == 0) { fail(DK_E_STREAM); return 0; }
-        return (code_ - rs_.low) / r_;
+        x_ = code_ - rs_.low;
+        if (r_ == 0 || static_cast<uint64_t>(x_) >= static_cast<uint64_t>(r_) * total) fail(DK_E_STREAM);
     }
-    inline uint32_t peek_pow2(unsigned shift) {
+    inline void begin_pow2(unsigned shift) {
         feed();
         r_ = (rs_.hi - rs_.low) >> shift;
-        if (r_ == 0) { fail(DK_E_STREAM); return 0; }
-        return (code_ - rs_.low) / r_;
+        x_ = code_ - rs_.low;
+        if (r_ == 0 || (static_cast<uint64_t>(x_) >> shift) >= r_) fail(DK_E_STREAM);
     }
+    // true when the decoded offset lies below `border` (i.e. offset < border)
+    inline bool below(uint32_t border) const { return static_cast<uint64_t>(x_) < static_cast<uint64_t>(r_) * border; }
     inline bool take(uint32_t from, uint32_t to) {
         int k = rs_.narrow(r_, from, to, [](uint8_t) {});
         if (k < 0) return fail(DK_E_STREAM);
@@ -127,7 +130,7 @@ private:
     RangeState rs_;
     const uint8_t *in_;
     size_t len_, pos_ = 0;
-    uint32_t code_ = 0, r_ = 0;
+    uint32_t code_ = 0, r_ = 0, x_ = 0;
     int pending_ = 4;
     int err_ = 0;
 };
@@ -151,11 +154,15 @@ struct FreqTable {
     inline uint32_t below(size_t v) const { uint32_t s = 0; for (size_t i = 0; i < v; ++i) s += f[i]; return s; }
     bool encode(Encoder &e, size_t v) const { const uint32_t lo = below(v); return e.put(total, lo, lo + f[v]); }
     bool decode(Decoder &d, size_t &v) const {
-        const uint32_t off = d.peek(total);
-        if (off >= total) return d.fail(DK_E_STREAM);
+        d.begin(total);
+        if (d.error()) return false;
         uint32_t lo = 0, hi = f[0];
         size_t k = 0;
-        while (hi <= off) { lo = hi; hi += f[++k]; }
+        while (!d.below(hi)) {
+            if (++k >= static_cast<size_t>(N)) return d.fail(DK_E_STREAM);
+            lo = hi;
+            hi += f[k];
+        }
         v = k;
         return d.take(lo, hi);
     }
@@ -170,12 +177,11 @@ inline bool encode_mix12(Encoder &e, const FreqTable<N> &a, const FreqTable<N> &
 }
 template <int N>
 inline bool decode_mix12(Decoder &d, const FreqTable<N> &a, const FreqTable<N> &b, size_t &v) {
-    const uint32_t total = a.total + 2u * b.total;
-    const uint32_t off = d.peek(total);
-    if (off >= total) return d.fail(DK_E_STREAM);
+    d.begin(a.total + 2u * b.total);
+    if (d.error()) return false;
     uint32_t lo = 0, hi = a.f[0] + 2u * b.f[0];
     size_t k = 0;
-    while (hi <= off) {
+    while (!d.below(hi)) {
         if (++k >= static_cast<size_t>(N)) return d.fail(DK_E_STREAM);
         lo = hi;
         hi += a.f[k] + 2u * b.f[k];
@@ -197,9 +203,9 @@ inline bool encode_bit_p(Encoder &e, uint32_t zero, bool one) {
     return one ? e.put_pow2(12, zero, 1u << 12) : e.put_pow2(12, 0, zero);
 }
 inline bool decode_bit_p(Decoder &d, uint32_t zero, bool &one) {
-    const uint32_t off = d.peek_pow2(12);
-    if (off >= (1u << 12)) return d.fail(DK_E_STREAM);
-    one = off >= zero;
+    d.begin_pow2(12);
+    if (d.error()) return false;
+    one = !d.below(zero);
     return one ? d.take(zero, 1u << 12) : d.take(0, zero);
 }
 

@@ -116,7 +116,8 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_reduce(const uint64_t *__re
 }
 
 // one workgroup: exclusive scan of the per-tile aggregates (sum, sum, running max); totals -> mail[0..1]
-__global__ __launch_bounds__(1024) void k_rerank_scan(RerankAgg *__restrict__ agg, size_t ntiles, uint32_t *__restrict__ mail) {
+__global__ __launch_bounds__(1024) void k_rerank_scan(RerankAgg *__restrict__ agg, size_t ntiles, uint32_t *__restrict__ mail,
+                                                      uint32_t *__restrict__ gstart) {
     __shared__ uint32_t s_tmp[16 + 1];
     const int tid = threadIdx.x;
     const size_t per = (ntiles + 1023) / 1024;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(1024) void k_rerank_scan(RerankAgg *__restrict__ ag
         eh += r.heads;
         el = el > r.last_head ? el : r.last_head;
     }
-    if (tid == 0) { mail[0] = tot_s; mail[1] = tot_h; }
+    if (tid == 0) { mail[0] = tot_s; mail[1] = tot_h; gstart[tot_h] = tot_s; }  // sentinel: one past the last group
 }
 
 // pos_in == nullptr means slot a sits at SA position a (first rerank, straight after the initial sort)
@@ -148,7 +149,8 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
                                                             const uint32_t *__restrict__ pos_in, size_t count, int gshift,
                                                             const RerankAgg *__restrict__ agg, uint32_t *__restrict__ rank,
                                                             uint32_t *__restrict__ sa, uint32_t *__restrict__ out_idx,
-                                                            uint32_t *__restrict__ out_pos, uint32_t *__restrict__ out_gid) {
+                                                            uint32_t *__restrict__ out_pos, uint32_t *__restrict__ out_gid,
+                                                            uint32_t *__restrict__ gstart) {
     __shared__ uint32_t s_tmp[RR_WAVES + 1];
     const size_t a0 = static_cast<size_t>(blockIdx.x) * RR_TILE + static_cast<size_t>(threadIdx.x) * RR_IPT;
     bool head[RR_IPT], surv[RR_IPT], oldh[RR_IPT];
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
         if (!surv[j]) {
             sa[my_pos] = suffix;  // the group is a singleton: this suffix is in its final place
         } else {
-            if (head[j]) ++eh;
+            if (head[j]) { gstart[eh] = es; ++eh; }  // first slot of the surviving group in the new active list
             out_idx[es] = suffix;
             out_pos[es] = my_pos;
             out_gid[es] = eh - 1;
@@ -186,20 +188,8 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
     }
 }
 
-__global__ __launch_bounds__(256) void k_build_keys(const uint32_t *__restrict__ act_idx, const uint32_t *__restrict__ act_gid,
-                                                     const uint32_t *__restrict__ rank, uint32_t n, uint32_t h, int kbits,
-                                                     uint64_t *__restrict__ keys, size_t count) {
-    const size_t a = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (a >= count) return;
-    const uint64_t p = static_cast<uint64_t>(act_idx[a]) + h;
-    // rank of the suffix h symbols further on, shifted up by h; suffixes that end before that get n-1-i (< h), which
-    // orders them among themselves by "shorter first" and in front of every suffix that continues
-    const uint32_t r2 = p < n ? rank[p] + h : static_cast<uint32_t>(static_cast<uint64_t>(n) + h - 1 - p);
-    keys[a] = (static_cast<uint64_t>(act_gid[a]) << kbits) | r2;
-}
-
 int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_t *pos_in, size_t count, int gshift, uint32_t *rank,
-           uint32_t *sa, uint32_t *out_idx, uint32_t *out_pos, uint32_t *out_gid, size_t *active, size_t *groups) {
+           uint32_t *sa, uint32_t *out_idx, uint32_t *out_pos, uint32_t *out_gid, uint32_t *gstart) {
     const size_t ntiles = div_up(count, RR_TILE);
     const size_t mark = ctx->ws_mark();
     RerankAgg *agg = ctx->ws_alloc<RerankAgg>(ntiles);
@@ -211,17 +201,180 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
     }
     {
         LaunchScope ls(ctx, K_RERANK_SCAN, 32.0 * ntiles);
-        k_rerank_scan<<<dim3(1), dim3(1024), 0, st>>>(agg, ntiles, ctx->d_mail);
+        k_rerank_scan<<<dim3(1), dim3(1024), 0, st>>>(agg, ntiles, ctx->d_mail, gstart);
     }
     {
         LaunchScope ls(ctx, K_RERANK_APPLY, 8.0 * count + 4.0 * count + 4.0 * count + 12.0 * count);
-        k_rerank_apply<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gshift, agg, rank, sa, out_idx, out_pos, out_gid);
+        k_rerank_apply<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gshift, agg, rank, sa, out_idx, out_pos, out_gid, gstart);
     }
     DK_HIP(ctx, hipGetLastError());
-    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    ctx->ws_release(mark);
+    return DK_OK;
+}
+
+// ---- big / small classification of the groups of the next round ---------------------------------------------------
+// A group of more than LS_MAX members goes through the global radix sort; bigstart[g] = number of slots in big groups
+// before group g (exclusive scan of the big sizes), bigstart[groups] = total -> mail[2].
+constexpr int LS_MAX = 64;
+constexpr int BG_IPT = 16;
+constexpr int BG_TILE = 256 * BG_IPT;
+
+__device__ __forceinline__ uint32_t big_size(const uint32_t *__restrict__ gstart, size_t g, size_t groups) {
+    if (g >= groups) return 0;
+    const uint32_t sz = gstart[g + 1] - gstart[g];
+    return sz > static_cast<uint32_t>(LS_MAX) ? sz : 0u;
+}
+// `groups` is read from mail[1] on the device: the host does not know it yet when these kernels are enqueued
+__global__ __launch_bounds__(256) void k_big_reduce(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ mail,
+                                                     uint32_t *__restrict__ part) {
+    __shared__ uint32_t s_w[RR_WAVES];
+    const size_t groups = mail[1];
+    const size_t g0 = static_cast<size_t>(blockIdx.x) * BG_TILE + static_cast<size_t>(threadIdx.x) * BG_IPT;
+    uint32_t sum = 0;
+    if (g0 < groups) {
+#pragma unroll
+        for (int j = 0; j < BG_IPT; ++j) sum += big_size(gstart, g0 + j, groups);
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(1024) void k_big_spine(uint32_t *__restrict__ part, size_t ntiles, uint32_t *__restrict__ mail,
+                                                    uint32_t *__restrict__ bigstart) {
+    __shared__ uint32_t s_tmp[16 + 1];
+    const size_t per = (ntiles + 1023) / 1024;
+    const size_t b0 = static_cast<size_t>(threadIdx.x) * per;
+    const size_t b1 = b0 + per < ntiles ? b0 + per : ntiles;
+    uint32_t sum = 0;
+    for (size_t b = b0; b < b1; ++b) sum += part[b];
+    uint32_t total;
+    uint32_t run = block_excl_sum<16>(sum, s_tmp, &total);
+    for (size_t b = b0; b < b1; ++b) {
+        const uint32_t v = part[b];
+        part[b] = run;
+        run += v;
+    }
+    if (threadIdx.x == 0) { mail[2] = total; bigstart[mail[1]] = total; }
+}
+__global__ __launch_bounds__(256) void k_big_apply(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ mail,
+                                                    const uint32_t *__restrict__ part, uint32_t *__restrict__ bigstart) {
+    __shared__ uint32_t s_tmp[RR_WAVES + 1];
+    const size_t groups = mail[1];
+    const size_t g0 = static_cast<size_t>(blockIdx.x) * BG_TILE + static_cast<size_t>(threadIdx.x) * BG_IPT;
+    uint32_t v[BG_IPT], sum = 0;
+#pragma unroll
+    for (int j = 0; j < BG_IPT; ++j) { v[j] = big_size(gstart, g0 + j, groups); sum += v[j]; }
+    uint32_t run = part[blockIdx.x] + block_excl_sum<RR_WAVES>(sum, s_tmp, nullptr);
+#pragma unroll
+    for (int j = 0; j < BG_IPT; ++j) {
+        if (g0 + j < groups) bigstart[g0 + j] = run;
+        run += v[j];
+    }
+}
+
+// ---- one doubling round for the small groups, entirely inside a workgroup -------------------------------------------
+// Tile of LS_TILE slots (+ LS_MAX halo slots on both sides, so that every small group touching the tile is visible):
+// gather rank2 for every slot into LDS, then each slot counts the members of its group that sort before it (O(group size)
+// LDS reads) and writes itself to its place inside the group's slot range.  Slots of big groups are copied, in slot order,
+// to the big list that the global radix sort handles.
+constexpr int LS_BLOCK = 256;
+constexpr int LS_IPT = 8;
+constexpr int LS_TILE = LS_BLOCK * LS_IPT;
+
+__device__ __forceinline__ uint32_t rank2_of(const uint32_t *__restrict__ rank, uint32_t suffix, uint32_t n, uint32_t h) {
+    // rank of the suffix h symbols further on, shifted up by h; suffixes that end before that get n-1-i (< h), which
+    // orders them among themselves by "shorter first" and in front of every suffix that continues
+    const uint64_t p = static_cast<uint64_t>(suffix) + h;
+    return p < n ? rank[p] + h : static_cast<uint32_t>(static_cast<uint64_t>(n) + h - 1 - p);
+}
+
+__global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__restrict__ act_idx, const uint32_t *__restrict__ act_gid,
+                                                          const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ bigstart,
+                                                          const uint32_t *__restrict__ rank, uint32_t n, uint32_t h, int kbits,
+                                                          size_t count, uint64_t *__restrict__ key_out, uint32_t *__restrict__ idx_out,
+                                                          uint64_t *__restrict__ bkeys, uint32_t *__restrict__ bidx) {
+    __shared__ uint32_t s_r2[LS_TILE + 2 * LS_MAX];
+    const int tid = threadIdx.x;
+    const size_t b0 = static_cast<size_t>(blockIdx.x) * LS_TILE;
+    uint32_t my_idx[LS_IPT], my_r2[LS_IPT];
+#pragma unroll
+    for (int k = 0; k < LS_IPT; ++k) {
+        const size_t a = b0 + static_cast<size_t>(k) * LS_BLOCK + tid;
+        if (a < count) {
+            my_idx[k] = act_idx[a];
+            my_r2[k] = rank2_of(rank, my_idx[k], n, h);
+            s_r2[LS_MAX + k * LS_BLOCK + tid] = my_r2[k];
+        }
+    }
+    if (tid < 2 * LS_MAX) {  // halo: LS_MAX slots before the tile, LS_MAX after
+        const bool left = tid < LS_MAX;
+        const size_t off = left ? static_cast<size_t>(tid) : static_cast<size_t>(LS_TILE) + LS_MAX + (tid - LS_MAX);
+        // slot index = b0 - LS_MAX + off; guard both ends of the list
+        if (b0 + off >= static_cast<size_t>(LS_MAX) && b0 + off - LS_MAX < count) {
+            const size_t a = b0 + off - LS_MAX;
+            s_r2[off] = rank2_of(rank, act_idx[a], n, h);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < LS_IPT; ++k) {
+        const size_t a = b0 + static_cast<size_t>(k) * LS_BLOCK + tid;
+        if (a >= count) continue;
+        const uint32_t g = act_gid[a];
+        const uint32_t gs = gstart[g], ge = gstart[g + 1];
+        const uint64_t key = (static_cast<uint64_t>(g) << kbits) | my_r2[k];
+        if (ge - gs <= static_cast<uint32_t>(LS_MAX)) {
+            const uint32_t mine = my_r2[k];
+            // LDS index of slot b is b - (b0 - LS_MAX) = b + LS_MAX - b0 (never negative: gs >= a - LS_MAX + 1)
+            const uint32_t base = static_cast<uint32_t>(LS_MAX) - static_cast<uint32_t>(b0);  // mod 2^32 arithmetic
+            uint32_t before = 0;
+            for (uint32_t b = gs; b < ge; ++b) {
+                const uint32_t v = s_r2[b + base];
+                before += (v < mine) || (v == mine && b < static_cast<uint32_t>(a));
+            }
+            key_out[gs + before] = key;
+            idx_out[gs + before] = my_idx[k];
+        } else {
+            const uint32_t bo = bigstart[g] + (static_cast<uint32_t>(a) - gs);
+            bkeys[bo] = key;
+            bidx[bo] = my_idx[k];
+        }
+    }
+}
+
+// sorted big list -> back into the slots of the big groups (a sorted element stays inside its group's slot range)
+__global__ __launch_bounds__(256) void k_big_back(const uint64_t *__restrict__ bkeys, const uint32_t *__restrict__ bidx, size_t nbig,
+                                                   int kbits, const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ bigstart,
+                                                   uint64_t *__restrict__ key_out, uint32_t *__restrict__ idx_out) {
+    const size_t bo = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (bo >= nbig) return;
+    const uint64_t key = bkeys[bo];
+    const uint32_t g = static_cast<uint32_t>(key >> kbits);
+    const uint32_t a = gstart[g] + (static_cast<uint32_t>(bo) - bigstart[g]);
+    key_out[a] = key;
+    idx_out[a] = bidx[bo];
+}
+
+// enqueue the classification of the groups rerank() just produced and read back (active, groups, big slots)
+int classify_and_read(dk_ctx *ctx, size_t max_groups, uint32_t *gstart, uint32_t *bigstart, size_t *active, size_t *groups, size_t *nbig) {
+    hipStream_t st = ctx->stream;
+    const size_t mark = ctx->ws_mark();
+    const size_t ntiles = div_up(max_groups + 1, BG_TILE);
+    uint32_t *part = ctx->ws_alloc<uint32_t>(ntiles);
+    if (!part) return DK_E_NOMEM;
+    {
+        LaunchScope ls(ctx, K_RERANK_SCAN, 8.0 * max_groups);
+        k_big_reduce<<<dim3(ntiles), dim3(256), 0, st>>>(gstart, ctx->d_mail, part);
+        k_big_spine<<<dim3(1), dim3(1024), 0, st>>>(part, ntiles, ctx->d_mail, bigstart);
+        k_big_apply<<<dim3(ntiles), dim3(256), 0, st>>>(gstart, ctx->d_mail, part, bigstart);
+    }
+    DK_HIP(ctx, hipGetLastError());
+    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     DK_HIP(ctx, hipStreamSynchronize(st));
     *active = ctx->h_mail[0];
     *groups = ctx->h_mail[1];
+    *nbig = ctx->h_mail[2];
     ctx->ws_release(mark);
     return DK_OK;
 }
@@ -260,13 +413,17 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     const int bits = static_cast<int>(ceil_log2_u64(sigma));  // 1..8
     const int spk = 64 / bits;                                // symbols per key: 8 (bytes) .. 32 (ACGT) .. 64 (binary)
 
-    uint64_t *keys = ctx->ws_alloc<uint64_t>(n), *keys_alt = ctx->ws_alloc<uint64_t>(n);
+    uint64_t *keys = ctx->ws_alloc<uint64_t>(n), *keys_alt = ctx->ws_alloc<uint64_t>(n), *keys_3 = ctx->ws_alloc<uint64_t>(n);
     uint32_t *vals = ctx->ws_alloc<uint32_t>(n), *vals_alt = ctx->ws_alloc<uint32_t>(n);
+    uint32_t *vals_3 = ctx->ws_alloc<uint32_t>(n), *vals_4 = ctx->ws_alloc<uint32_t>(n);
     uint32_t *rank = ctx->ws_alloc<uint32_t>(n);
     uint32_t *pos = ctx->ws_alloc<uint32_t>(n), *pos_alt = ctx->ws_alloc<uint32_t>(n);
     uint32_t *gid = ctx->ws_alloc<uint32_t>(n), *gid_alt = ctx->ws_alloc<uint32_t>(n);
+    uint32_t *gstart = ctx->ws_alloc<uint32_t>(n / 2 + 2), *bigstart = ctx->ws_alloc<uint32_t>(n / 2 + 2);
     uint8_t *d_code = reinterpret_cast<uint8_t *>(ctx->d_mail + 512);
-    if (!keys || !keys_alt || !vals || !vals_alt || !rank || !pos || !pos_alt || !gid || !gid_alt) return DK_E_NOMEM;
+    if (!keys || !keys_alt || !keys_3 || !vals || !vals_alt || !vals_3 || !vals_4 || !rank || !pos || !pos_alt || !gid || !gid_alt ||
+        !gstart || !bigstart)
+        return DK_E_NOMEM;
     DK_HIP(ctx, hipMemcpyAsync(d_code, code, 256, hipMemcpyHostToDevice, st));
 
     // 2.-3. initial keys and sort
@@ -278,34 +435,51 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     DK_TRY(sort_pairs(ctx, keys, keys_alt, vals, vals_alt, n, 0, bits * spk));
 
     // 4. first rerank (slots are SA positions)
-    size_t active = 0, groups = 0;
-    DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, rank, d_sa, vals_alt, pos, gid, &active, &groups));
+    size_t active = 0, groups = 0, nbig = 0;
+    DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, rank, d_sa, vals_alt, pos, gid, gstart));
+    DK_TRY(classify_and_read(ctx, n / 2, gstart, bigstart, &active, &groups, &nbig));
     std::swap(vals, vals_alt);  // vals = suffix indices of the active list
 
     // 5. doubling rounds
     uint64_t h = static_cast<uint64_t>(spk);
     static const bool trace = getenv("DK_TRACE") != nullptr;
-    if (trace) fprintf(stderr, "[dk] n=%zu sigma=%u bits=%d spk=%d: after init sort active=%zu groups=%zu\n", n, sigma, bits, spk, active, groups);
+    if (trace)
+        fprintf(stderr, "[dk] n=%zu sigma=%u bits=%d spk=%d: after init sort active=%zu groups=%zu big=%zu\n", n, sigma, bits, spk,
+                active, groups, nbig);
     while (active > 0) {
         if (ctx->stats.rounds > 40) return ctx->fail(DK_E_INTERNAL, "suffix_array: no convergence after 40 rounds");
         const uint32_t h_eff = static_cast<uint32_t>(std::min<uint64_t>(h, n));
         const int kbits = static_cast<int>(ceil_log2_u64(static_cast<uint64_t>(n) + h_eff));
         const int gbits = static_cast<int>(ceil_log2_u64(groups));
+        // small groups: sorted in LDS; big groups: copied to (keys_alt, vals_3) for the global sort
         {
-            LaunchScope ls(ctx, K_BUILD_KEYS, 8.0 * active + 4.0 * active + 8.0 * active);
-            k_build_keys<<<dim3(div_up(active, 256)), dim3(256), 0, st>>>(vals, gid, rank, static_cast<uint32_t>(n), h_eff, kbits,
-                                                                         keys, active);
+            LaunchScope ls(ctx, K_BUILD_KEYS, 8.0 * active + 4.0 * active + 12.0 * active);
+            k_round_local<<<dim3(div_up(active, LS_TILE)), dim3(LS_BLOCK), 0, st>>>(vals, gid, gstart, bigstart, rank, static_cast<uint32_t>(n),
+                                                                                    h_eff, kbits, active, keys, vals_alt, keys_alt, vals_3);
         }
         DK_HIP(ctx, hipGetLastError());
-        DK_TRY(sort_pairs(ctx, keys, keys_alt, vals, vals_alt, active, 0, kbits + gbits));
-        size_t next_active = 0, next_groups = 0;
-        DK_TRY(rerank(ctx, keys, vals, pos, active, kbits, rank, d_sa, vals_alt, pos_alt, gid_alt, &next_active, &next_groups));
-        std::swap(vals, vals_alt);
+        if (nbig > 0) {
+            uint64_t *bk = keys_alt, *bk_alt = keys_3;
+            uint32_t *bv = vals_3, *bv_alt = vals_4;
+            DK_TRY(sort_pairs(ctx, bk, bk_alt, bv, bv_alt, nbig, 0, kbits + gbits));
+            {
+                LaunchScope ls(ctx, K_MISC, 24.0 * nbig);
+                k_big_back<<<dim3(div_up(nbig, 256)), dim3(256), 0, st>>>(bk, bv, nbig, kbits, gstart, bigstart, keys, vals_alt);
+            }
+            DK_HIP(ctx, hipGetLastError());
+        }
+        // keys / vals_alt now hold every group sorted by rank2 in its own slot range
+        size_t next_active = 0, next_groups = 0, next_big = 0;
+        DK_TRY(rerank(ctx, keys, vals_alt, pos, active, kbits, rank, d_sa, vals, pos_alt, gid_alt, gstart));
+        DK_TRY(classify_and_read(ctx, active / 2, gstart, bigstart, &next_active, &next_groups, &next_big));
         std::swap(pos, pos_alt);
         std::swap(gid, gid_alt);
-        if (trace) fprintf(stderr, "[dk] round %u h=%llu sorted=%zu bits=%d -> active=%zu groups=%zu\n", ctx->stats.rounds, (unsigned long long)h, active, kbits + gbits, next_active, next_groups);
+        if (trace)
+            fprintf(stderr, "[dk] round %u h=%llu slots=%zu big=%zu bits=%d -> active=%zu groups=%zu big=%zu\n", ctx->stats.rounds,
+                    (unsigned long long)h, active, nbig, kbits + gbits, next_active, next_groups, next_big);
         active = next_active;
         groups = next_groups;
+        nbig = next_big;
         ctx->stats.rounds += 1;
         h *= 2;
     }
