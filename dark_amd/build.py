@@ -30,7 +30,9 @@ def build(force=False, verbose=False):
         op = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
         objs.append(op)
         if force or not os.path.exists(op) or os.path.getmtime(op) < newest_dep:
-            cmd = [HIPCC] + CXXFLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", sp, "-o", op]
+            # host-only sources: x86-64-v3 (AVX2, BMI2, LZCNT, MOVBE) -- every host that carries an MI355X has it
+            extra = ["-x", "hip"] if src.endswith(".hip") else ["-march=x86-64-v3"]
+            cmd = [HIPCC] + CXXFLAGS + extra + ["-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

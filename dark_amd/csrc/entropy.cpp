@@ -2,6 +2,9 @@
 #include "entropy.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <thread>
 #include <vector>
 
 namespace dk {
@@ -36,7 +39,8 @@ inline void DarkModel::adapt(PerSymbol &c, uint32_t dist, int log_diff) {  // da
     c.avg_dist += (a * (static_cast<int64_t>(dist) - c.avg_dist)) >> 3;  // floor, like isize >> 3
 }
 
-bool DarkModel::encode(uint32_t dist, uint8_t symbol, Encoder &e) {  // dark.rs:180-232
+template <class E>
+bool DarkModel::encode(uint32_t dist, uint8_t symbol, E &e) {  // dark.rs:180-232
     if (dist >= 0x7FFFFFFFu) return false;  // log would reach 32: freq_mantissa has 32 rows
     const uint32_t v = dist + 1;
     const unsigned log = bit_length(v);
@@ -142,7 +146,8 @@ uint32_t ExpModel::log_fixed(uint32_t d) {  // exp.rs:34-43 with its integer qui
     if (d <= 12) return (5u << kFixedBase) + (d & 3) * (kFixedBase >> 2);
     return (6u << kFixedBase) + (d - 12) * (kFixedBase >> 12);
 }
-bool ExpModel::encode(uint32_t dist, uint8_t symbol, Encoder &e) {  // exp.rs:58-78
+template <class E>
+bool ExpModel::encode(uint32_t dist, uint8_t symbol, E &e) {  // exp.rs:58-78
     const uint32_t log = avg_log_[symbol];
     const uint32_t w2 = log & kFixedMask, w1 = kFixedMask + 1 - w2;
     uint16_t *m1 = prob_[log >> kFixedBase], *m2 = prob_[(log >> kFixedBase) + 1];
@@ -188,7 +193,8 @@ void YbsModel::track(PerSymbol &c, uint32_t log) {  // ybs.rs:33-38
     c.last_diff = log > c.avg_log ? log - c.avg_log : c.avg_log - log;
     c.avg_log = (a * log + c.avg_log) / (a + 1);
 }
-bool YbsModel::encode(uint32_t dist, uint8_t symbol, Encoder &e) {  // ybs.rs:89-127
+template <class E>
+bool YbsModel::encode(uint32_t dist, uint8_t symbol, E &e) {  // ybs.rs:89-127
     constexpr uint32_t kMaxLow = 12;
     const uint32_t group = dist < 4 ? dist : bit_length(dist) + 1;
     PerSymbol &c = sym_[symbol];
@@ -253,7 +259,8 @@ bool YbsModel::decode(uint8_t symbol, Decoder &d, uint32_t &dist) {  // ybs.rs:1
 // ------------------------------------------------------------------------------------------------------------------
 namespace { constexpr unsigned kSimpleUp[4] = {10, 8, 7, 6}; }  // simple.rs:38
 void SimpleModel::reset() { for (auto &t : freq_) t.flat(); }
-bool SimpleModel::encode(uint32_t dist, uint8_t, Encoder &e) {  // simple.rs:51-64
+template <class E>
+bool SimpleModel::encode(uint32_t dist, uint8_t, E &e) {  // simple.rs:51-64
     const uint32_t head = std::min<uint32_t>(0xFF, dist);
     if (!freq_[0].encode(e, head)) return false;
     freq_[0].bump(head, kSimpleUp[0], 1);
@@ -301,8 +308,8 @@ uint64_t model_max_block(int model_id) {
 namespace {
 
 // src/block/dc.rs:54-90 with any model M
-template <class M>
-int write_stream(M &model, const DcStream &s, Encoder &e) {
+template <class M, class E>
+int write_stream(M &model, const DcStream &s, E &e) {
     const size_t n = s.n;
     auto code = [&](uint32_t v, uint8_t sym) { return model.encode(v, sym, e); };
     // Init-table RLE: alternating present / absent run lengths over symbols 0..254; every present symbol is followed
@@ -393,7 +400,13 @@ int dc_rebuild(uint32_t const init[256], uint8_t *out, size_t n, F &&next_dist, 
         const uint8_t sym = order[0];
         const uint64_t stop = next[order[1]];
         if (stop > n || stop < i) return DK_E_STREAM;
-        std::memset(out + i, sym, stop - i);
+        if (stop - i <= 16 && i + 16 <= n) {  // BWT runs are short: one unconditional 16-byte splat beats a memset call
+            uint8_t splat[16];
+            std::memset(splat, sym, 16);
+            std::memcpy(out + i, splat, 16);
+        } else {
+            std::memset(out + i, sym, stop - i);
+        }
         i = stop;
         uint32_t d;
         if (int rc = next_dist(sym, &d)) return rc;
@@ -451,12 +464,136 @@ int with_model(int model_id, F &&f) {
 
 }  // namespace
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// EventPipe: ring of batches between the modelling thread (producer) and the coding thread (consumer)
+// ------------------------------------------------------------------------------------------------------------------
+class EventPipe {
+public:
+    static constexpr uint32_t kBatch = 1u << 12;  // events per batch (32 KiB: stays in the consumer's L2)
+    static constexpr int kSlots = 16;
+    static constexpr uint32_t kEnd = 0x80000000u;  // OR-ed into the count of the last batch
+    EventPipe() : buf_(new CodeEvent[static_cast<size_t>(kSlots) * kBatch]) {
+        for (auto &c : ready_) c.store(0, std::memory_order_relaxed);
+    }
+    CodeEvent *slot(int i) { return buf_.get() + static_cast<size_t>(i) * kBatch; }
+    // producer: wait until slot i has been consumed
+    void acquire_free(int i) {
+        unsigned spins = 0;
+        while (ready_[i].load(std::memory_order_acquire) != 0) backoff(spins);
+    }
+    void publish(int i, uint32_t count_and_flags) { ready_[i].store(count_and_flags | kFull, std::memory_order_release); }
+    // consumer: wait until slot i is full; returns count | kEnd
+    uint32_t acquire_full(int i) {
+        unsigned spins = 0;
+        uint32_t v;
+        while ((v = ready_[i].load(std::memory_order_acquire)) == 0) backoff(spins);
+        return v & ~kFull;
+    }
+    void release(int i) { ready_[i].store(0, std::memory_order_release); }
+
+private:
+    static constexpr uint32_t kFull = 0x40000000u;
+    static void backoff(unsigned &spins) {
+        // busy-wait: a hand-off is expected every few microseconds; yielding to the scheduler costs far more than that
+        if (++spins < (1u << 20)) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        } else {
+            std::this_thread::yield();
+        }
+    }
+    std::unique_ptr<CodeEvent[]> buf_;
+    alignas(64) std::atomic<uint32_t> ready_[kSlots];
+};
+
+EventSink::EventSink(EventPipe &p) : pipe_(p) {
+    pipe_.acquire_free(0);
+    cur_ = pipe_.slot(0);
+    cap_ = EventPipe::kBatch;
+}
+void EventSink::flush() {
+    pipe_.publish(slot_, fill_);
+    slot_ = (slot_ + 1) % EventPipe::kSlots;
+    pipe_.acquire_free(slot_);
+    cur_ = pipe_.slot(slot_);
+    fill_ = 0;
+}
+bool EventSink::finish() {
+    if (!cur_) return err_ == 0;  // already finished
+    pipe_.publish(slot_, fill_ | EventPipe::kEnd);
+    fill_ = 0;
+    cur_ = nullptr;
+    return err_ == 0;
+}
+
+namespace {
+
+// consumer side: the range coder over the recorded intervals
+int drain_pipe(EventPipe &pipe, uint8_t *out, size_t cap, size_t *out_len) {
+    RangeState rs;
+    size_t len = 0;
+    int err = DK_OK;
+    for (int slot = 0;; slot = (slot + 1) % EventPipe::kSlots) {
+        const uint32_t v = pipe.acquire_full(slot);
+        const uint32_t count = v & ~EventPipe::kEnd;
+        const CodeEvent *ev = pipe.slot(slot);
+        if (!err && len + 4 * static_cast<size_t>(count) + 12 > cap) err = DK_E_CAPACITY;  // keep draining so the producer can end
+        if (!err) {
+            uint8_t *p = out + len;
+            for (uint32_t k = 0; k < count; ++k) {
+                const CodeEvent e = ev[k];
+                const uint32_t span = rs.hi - rs.low;
+                const uint32_t r = e.total ? span / e.total : span >> 12;
+                const int nb = r ? rs.narrow(r, e.from, e.to, p) : -1;
+                if (nb < 0) { err = DK_E_INTERNAL; break; }
+                p += nb;
+            }
+            len = static_cast<size_t>(p - out);
+        }
+        pipe.release(slot);
+        if (v & EventPipe::kEnd) break;
+    }
+    if (!err) {
+        if (len + 4 > cap) err = DK_E_CAPACITY;
+        else for (int i = 0; i < 4; ++i) out[len++] = static_cast<uint8_t>(rs.low >> (24 - 8 * i));  // ari::Encoder::finish
+    }
+    *out_len = len;
+    return err;
+}
+
+template <class M>
+int encode_two_threads(M &model, const DcStream &s, uint8_t *out, size_t cap, size_t *out_len) {
+    EventPipe pipe;
+    int producer_rc = DK_OK;
+    std::thread producer([&] {
+        EventSink sink(pipe);
+        producer_rc = write_stream(model, s, sink);
+        if (producer_rc != DK_OK) sink.finish();  // write_stream finishes the sink itself on success
+    });
+    int rc = drain_pipe(pipe, out, cap, out_len);
+    producer.join();
+    return producer_rc ? producer_rc : rc;
+}
+
+bool use_two_threads(size_t m) {
+    static const int mode = [] { const char *e = getenv("DK_ENTROPY_THREADS"); return e ? atoi(e) : 0; }();
+    // Measured on the GPU box (EPYC 9575F): the out-of-order core already overlaps the model updates with the coder's dependency
+    // chain, and the cross-core hand-off costs more than the split saves (40 vs 36 ns per distance).  Opt-in only.
+    (void)m;
+    return mode >= 2;
+}
+
+}  // namespace
+
 int encode_block_stream(int model_id, const DcStream &s, uint8_t *out, size_t cap, size_t *out_len) {
     if (!s.init || (!s.dist && s.m) || (!s.sym && s.m) || !out || !out_len) return DK_E_ARG;
     if (model_id == DK_MODEL_RAWDC) return write_records(s, out, cap, out_len);
     if (s.n > model_max_block(model_id)) return DK_E_MODEL;
     return with_model(model_id, [&](auto &model) {
         model.reset();  // Encoder::new resets the model (src/block/dc.rs:31)
+        if (use_two_threads(s.m)) return encode_two_threads(model, s, out, cap, out_len);
         Encoder e(out, cap);
         int rc = write_stream(model, s, e);
         *out_len = e.size();

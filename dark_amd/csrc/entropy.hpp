@@ -24,23 +24,26 @@ constexpr uint32_t kTopMask = 0xFF000000u;
 
 struct RangeState {
     uint32_t low = 0, hi = 0xFFFFFFFFu;
-    // Narrow to [low + r*from, low + r*to) and renormalise; bytes leaving the top go to `emit`.
-    // Returns the number of bytes shifted out, or -1 when the interval is degenerate.
-    template <class Emit>
-    inline int narrow(uint32_t r, uint32_t from, uint32_t to, Emit &&emit) {
+    // Narrow to [low + r*from, low + r*to) and renormalise.  The reference loop is
+    //     loop { if top bytes differ { if hi-lo > threshold break; cut at the byte border }  emit lo>>24; lo <<= 8; hi <<= 8 }
+    // i.e. "shift out every equal leading byte, then stop if the range is wide enough, else cut and go round again".
+    // All equal leading bytes leave in one step here (count-leading-zeros of lo^hi), through an unconditional 4-byte store:
+    // `out` must have 8 writable bytes.  Returns the number of bytes shifted out (the reference allows at most 4), or -1.
+    inline int narrow(uint32_t r, uint32_t from, uint32_t to, uint8_t *out) {
         uint32_t lo = low + r * from, h = low + r * to;
         int shifted = 0;
         for (;;) {
-            if ((lo ^ h) & kTopMask) {
-                if (h - lo > kRangeThreshold) break;
-                const uint32_t lim = h & kTopMask;
-                if (h - lim >= lim - lo) lo = lim; else h = lim - 1;
-            }
-            if (shifted == 4) return -1;
-            emit(static_cast<uint8_t>(lo >> 24));
-            ++shifted;
-            lo <<= 8;
-            h <<= 8;
+            const uint32_t x = lo ^ h;
+            const int nb = x ? (__builtin_clz(x) >> 3) : 4;  // equal leading bytes (4 only if the interval is empty)
+            const uint32_t be = __builtin_bswap32(lo);
+            std::memcpy(out + shifted, &be, 4);
+            shifted += nb;
+            if (shifted > 4 || nb == 4) return -1;
+            lo <<= 8 * nb;
+            h <<= 8 * nb;
+            if (__builtin_expect(h - lo > kRangeThreshold, 1)) break;
+            const uint32_t lim = h & kTopMask;
+            if (h - lim >= lim - lo) lo = lim; else h = lim - 1;
         }
         low = lo;
         hi = h;
@@ -75,10 +78,18 @@ public:
 
 private:
     inline bool emit_narrow(uint32_t r, uint32_t from, uint32_t to) {
-        if (len_ + 4 > cap_) return fail(DK_E_CAPACITY);
-        uint8_t *p = out_ + len_;
-        int k = rs_.narrow(r, from, to, [&](uint8_t b) { *p++ = b; });
+        if (__builtin_expect(len_ + 8 > cap_, 0)) return slow_narrow(r, from, to);
+        const int k = rs_.narrow(r, from, to, out_ + len_);
+        if (__builtin_expect(k < 0, 0)) return fail(DK_E_INTERNAL);
+        len_ += static_cast<size_t>(k);
+        return true;
+    }
+    bool slow_narrow(uint32_t r, uint32_t from, uint32_t to) {  // within 8 bytes of the end of the caller's buffer
+        uint8_t tmp[8];
+        const int k = rs_.narrow(r, from, to, tmp);
         if (k < 0) return fail(DK_E_INTERNAL);
+        if (len_ + static_cast<size_t>(k) > cap_) return fail(DK_E_CAPACITY);
+        std::memcpy(out_ + len_, tmp, static_cast<size_t>(k));
         len_ += static_cast<size_t>(k);
         return true;
     }
@@ -109,7 +120,8 @@ public:
     // true when the decoded offset lies below `border` (i.e. offset < border)
     inline bool below(uint32_t border) const { return static_cast<uint64_t>(x_) < static_cast<uint64_t>(r_) * border; }
     inline bool take(uint32_t from, uint32_t to) {
-        int k = rs_.narrow(r_, from, to, [](uint8_t) {});
+        uint8_t scratch[8];
+        const int k = rs_.narrow(r_, from, to, scratch);
         if (k < 0) return fail(DK_E_STREAM);
         pending_ = k;
         return err_ == 0;
@@ -120,6 +132,17 @@ public:
 
 private:
     inline void feed() {
+        const unsigned k = static_cast<unsigned>(pending_);
+        if (__builtin_expect(k == 0, 0)) return;
+        if (__builtin_expect(pos_ + 4 <= len_, 1)) {  // take k (1..4) bytes out of one unconditional 4-byte big-endian load
+            uint32_t be;
+            std::memcpy(&be, in_ + pos_, 4);
+            const uint64_t w = __builtin_bswap32(be);
+            code_ = static_cast<uint32_t>(((static_cast<uint64_t>(code_) << 32) | w) >> (32 - 8 * k));
+            pos_ += k;
+            pending_ = 0;
+            return;
+        }
         while (pending_) {
             uint8_t b = 0;
             if (pos_ < len_) b = in_[pos_++]; else fail(DK_E_STREAM);  // read_u8 Err -> the reference unwraps (panics)
@@ -132,6 +155,43 @@ private:
     size_t len_, pos_ = 0;
     uint32_t code_ = 0, r_ = 0, x_ = 0;
     int pending_ = 4;
+    int err_ = 0;
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// Two-thread encode: the models never read the coder's state, so one thread can run the (serial) modelling and hand the
+// resulting intervals to a second thread that runs the (serial) range coder.  Same intervals in the same order -> the same
+// bytes.  EventSink has the put/put_pow2 interface of Encoder; EventPipe is the single-producer single-consumer ring.
+// ------------------------------------------------------------------------------------------------------------------
+struct CodeEvent { uint16_t from, to, total, pad; };  // total == 0: power-of-two total 1 << 12
+class EventPipe;
+class EventSink {
+public:
+    explicit EventSink(EventPipe &p);
+    inline bool put(uint32_t total, uint32_t from, uint32_t to) {
+        if (!(from < to && to <= total && total < 65536u)) return fail(DK_E_INTERNAL);
+        push(CodeEvent{static_cast<uint16_t>(from), static_cast<uint16_t>(to), static_cast<uint16_t>(total), 0});
+        return true;
+    }
+    inline bool put_pow2(unsigned shift, uint32_t from, uint32_t to) {
+        if (!(shift == 12 && from < to && to <= 4096u)) return fail(DK_E_INTERNAL);
+        push(CodeEvent{static_cast<uint16_t>(from), static_cast<uint16_t>(to), 0, 0});
+        return true;
+    }
+    bool finish();  // flush the last batch and mark the end of the stream
+    int error() const { return err_; }
+    bool fail(int e) { if (!err_) err_ = e; return false; }
+
+private:
+    inline void push(const CodeEvent &ev) {
+        cur_[fill_++] = ev;
+        if (fill_ == cap_) flush();
+    }
+    void flush();
+    EventPipe &pipe_;
+    CodeEvent *cur_ = nullptr;
+    uint32_t fill_ = 0, cap_ = 0;
+    int slot_ = 0;
     int err_ = 0;
 };
 
@@ -152,7 +212,7 @@ struct FreqTable {
         if (total >= kModelThreshold) halve();
     }
     inline uint32_t below(size_t v) const { uint32_t s = 0; for (size_t i = 0; i < v; ++i) s += f[i]; return s; }
-    bool encode(Encoder &e, size_t v) const { const uint32_t lo = below(v); return e.put(total, lo, lo + f[v]); }
+    template <class E> bool encode(E &e, size_t v) const { const uint32_t lo = below(v); return e.put(total, lo, lo + f[v]); }
     bool decode(Decoder &d, size_t &v) const {
         d.begin(total);
         if (d.error()) return false;
@@ -169,10 +229,11 @@ struct FreqTable {
 };
 
 // table::SumProxy::new(1, a, 2, b, 0): the only weighting the reference uses (dark.rs:194,243)
-template <int N>
-inline bool encode_mix12(Encoder &e, const FreqTable<N> &a, const FreqTable<N> &b, size_t v) {
+template <int N, class E>
+inline bool encode_mix12(E &e, const FreqTable<N> &a, const FreqTable<N> &b, size_t v) {
     uint32_t lo = 0;
-    for (size_t i = 0; i < v; ++i) lo += a.f[i] + 2u * b.f[i];
+#pragma GCC unroll 8
+    for (size_t i = 0; i < static_cast<size_t>(N); ++i) lo += i < v ? a.f[i] + 2u * b.f[i] : 0u;  // fixed trip count: no data-dependent branch
     return e.put(a.total + 2u * b.total, lo, lo + a.f[v] + 2u * b.f[v]);
 }
 template <int N>
@@ -194,19 +255,23 @@ struct BinFreq {  // total is always kModelThreshold = 1 << 12 in the reference'
     static constexpr unsigned kShift = 12;
     uint32_t zero;
     void flat() { zero = kModelThreshold >> 1; }
-    template <unsigned RATE> inline void learn(bool one) {
-        if (one) zero -= zero >> RATE; else zero += (kModelThreshold - zero) >> RATE;
+    template <unsigned RATE> inline void learn(bool one) {  // branch-free: the bit is data, not control
+        const uint32_t down = zero >> RATE, up = (kModelThreshold - zero) >> RATE;
+        zero += one ? (0u - down) : up;
     }
 };
 static_assert((1u << BinFreq::kShift) == kModelThreshold, "bin total must be a power of two");
-inline bool encode_bit_p(Encoder &e, uint32_t zero, bool one) {
-    return one ? e.put_pow2(12, zero, 1u << 12) : e.put_pow2(12, 0, zero);
+template <class E>
+inline bool encode_bit_p(E &e, uint32_t zero, bool one) {
+    const uint32_t from = one ? zero : 0u, to = one ? (1u << 12) : zero;
+    return e.put_pow2(12, from, to);
 }
 inline bool decode_bit_p(Decoder &d, uint32_t zero, bool &one) {
     d.begin_pow2(12);
     if (d.error()) return false;
     one = !d.below(zero);
-    return one ? d.take(zero, 1u << 12) : d.take(0, zero);
+    const uint32_t from = one ? zero : 0u, to = one ? (1u << 12) : zero;
+    return d.take(from, to);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -219,7 +284,7 @@ class DarkModel {  // src/model/dark.rs
 public:
     DarkModel() { reset(); }
     void reset();
-    bool encode(uint32_t dist, uint8_t symbol, Encoder &e);
+    template <class E> bool encode(uint32_t dist, uint8_t symbol, E &e);
     bool decode(uint8_t symbol, Decoder &d, uint32_t &dist);
 
 private:
@@ -236,7 +301,7 @@ class ExpModel {  // src/model/exp.rs
 public:
     ExpModel() { reset(); }
     void reset();
-    bool encode(uint32_t dist, uint8_t symbol, Encoder &e);
+    template <class E> bool encode(uint32_t dist, uint8_t symbol, E &e);
     bool decode(uint8_t symbol, Decoder &d, uint32_t &dist);
 
 private:
@@ -249,7 +314,7 @@ class YbsModel {  // src/model/ybs.rs
 public:
     YbsModel() { reset(); }
     void reset();
-    bool encode(uint32_t dist, uint8_t symbol, Encoder &e);
+    template <class E> bool encode(uint32_t dist, uint8_t symbol, E &e);
     bool decode(uint8_t symbol, Decoder &d, uint32_t &dist);
 
 private:
@@ -265,7 +330,7 @@ class SimpleModel {  // src/model/simple.rs
 public:
     SimpleModel() { reset(); }
     void reset();
-    bool encode(uint32_t dist, uint8_t symbol, Encoder &e);
+    template <class E> bool encode(uint32_t dist, uint8_t symbol, E &e);
     bool decode(uint8_t symbol, Decoder &d, uint32_t &dist);
 
 private:
