@@ -151,9 +151,9 @@ __global__ __launch_bounds__(256) void k_dc_carry_c(uint32_t *__restrict__ tile_
     }
 }
 
-__device__ __forceinline__ uint32_t sel4(const uint32_t v[4], uint32_t k) {
-    return k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3]));
-}
+// LDS layout of a wave's 256-entry table: symbol c lives at word ((c & 63) << 2) | (c >> 6), so that lane l owns the four
+// consecutive words of symbols l, l+64, l+128, l+192 (one 16-byte read) and a single symbol is one broadcast read.
+__device__ __forceinline__ uint32_t tab_index(uint32_t c) { return ((c & 63u) << 2) | (c >> 6); }
 
 __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict__ L, size_t n, size_t ntiles,
                                                        const uint32_t *__restrict__ carry_last, const uint32_t *__restrict__ carry_lrun,
@@ -162,20 +162,23 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
                                                        uint32_t *__restrict__ init, uint32_t *__restrict__ final_last,
                                                        uint32_t *__restrict__ final_lrun) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[DC_WAVES][DC_PAD + DC_TILE + 16];
+    __shared__ __attribute__((aligned(16))) uint32_t s_pos[DC_WAVES][256];  // last position + 1 of every symbol (0 = not seen yet)
+    __shared__ __attribute__((aligned(16))) uint32_t s_run[DC_WAVES][256];  // run index + 1 of that occurrence
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t tile = static_cast<size_t>(blockIdx.x) * DC_WAVES + wave;
     if (tile >= ntiles) return;
     const size_t base = tile * DC_TILE;
     uint8_t *s = s_tile[wave];
+    uint32_t *pos = s_pos[wave], *run = s_run[wave];
     stage_tile(L, n, base, s, lane);
-    // lp[k] / lr[k]: last position + 1 and run index + 1 of symbol k*64 + lane (0 = not seen yet)
-    uint32_t lp[4], lr[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        lp[k] = carry_last[tile * 256 + k * 64 + lane];
-        lr[k] = carry_lrun[tile * 256 + k * 64 + lane];
+        pos[(lane << 2) | k] = carry_last[tile * 256 + k * 64 + lane];
+        run[(lane << 2) | k] = carry_lrun[tile * 256 + k * 64 + lane];
     }
-    uint32_t r = tile_run_base[tile];  // index of the next run to start
+    // wave-uniform values are pinned to scalar registers: the per-run loop below is scalar control flow
+    uint32_t r = __builtin_amdgcn_readfirstlane(tile_run_base[tile]);  // index of the next run to start
+    const uint32_t base32 = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int chunk = 0; chunk < DC_TILE / 64; ++chunk) {
@@ -188,22 +191,22 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
         while (m) {
             const int bit = __builtin_ctzll(m);
             m &= m - 1;
-            const uint32_t i = static_cast<uint32_t>(base + chunk * 64 + bit);
+            const uint32_t i = base32 + static_cast<uint32_t>(chunk * 64 + bit);
             const uint32_t cs = __builtin_amdgcn_readlane(c, bit);
             const uint32_t ps = __builtin_amdgcn_readlane(pc, bit);
-            if (i > 0) {  // the run of `ps` ended at i-1; it is run r-1
-                const uint32_t kk = ps >> 6, ll = ps & 63;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (static_cast<uint32_t>(k) == kk && static_cast<uint32_t>(lane) == ll) { lp[k] = i; lr[k] = r; }
+            if (i > 0) {  // the run of `ps` ended at i-1; it is run r-1.  Every lane stores the same word: no divergence.
+                pos[tab_index(ps)] = i;
+                run[tab_index(ps)] = r;
                 if (run_end && lane == 0) run_end[r - 1] = i - 1;
             }
-            const uint32_t b1 = __builtin_amdgcn_readlane(sel4(lp, cs >> 6), cs & 63);
-            const uint32_t rb1 = __builtin_amdgcn_readlane(sel4(lr, cs >> 6), cs & 63);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t b1 = __builtin_amdgcn_readfirstlane(pos[tab_index(cs)]);
+            const uint32_t rb1 = __builtin_amdgcn_readfirstlane(run[tab_index(cs)]);
+            const uint4 mine = *reinterpret_cast<const uint4 *>(pos + (lane << 2));
             uint32_t cnt = 0;
-            if (b1) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) cnt += static_cast<uint32_t>(__popcll(__ballot(lp[k] > b1)));
+            if (b1) {  // rank = number of symbols seen since the previous occurrence of cs
+                cnt = static_cast<uint32_t>(__popcll(__ballot(mine.x > b1)) + __popcll(__ballot(mine.y > b1)) +
+                                            __popcll(__ballot(mine.z > b1)) + __popcll(__ballot(mine.w > b1)));
             }
             if (lane == 0) {
                 if (b1) dist[rb1 - 1] = i - b1 - cnt;  // = i - b - rank - 1 with b = b1 - 1
@@ -216,15 +219,15 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
     }
     if (tile == ntiles - 1) {  // close the last run of the block and publish the final table for the sweep
         const uint32_t ps = L[n - 1];
-        const uint32_t kk = ps >> 6, ll = ps & 63;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (static_cast<uint32_t>(k) == kk && static_cast<uint32_t>(lane) == ll) { lp[k] = static_cast<uint32_t>(n); lr[k] = r; }
+        pos[tab_index(ps)] = static_cast<uint32_t>(n);
+        run[tab_index(ps)] = r;
         if (run_end && lane == 0) run_end[r - 1] = static_cast<uint32_t>(n - 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            final_last[k * 64 + lane] = lp[k];
-            final_lrun[k * 64 + lane] = lr[k];
+            final_last[k * 64 + lane] = pos[(lane << 2) | k];
+            final_lrun[k * 64 + lane] = run[(lane << 2) | k];
         }
     }
 }
