@@ -119,6 +119,8 @@ inline unsigned ceil_log2_u64(uint64_t v) {  // smallest b with (1 << b) >= v
 int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
                int begin_bit, int end_bit);
 int sort_check_error(dk_ctx *ctx);
+int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, size_t count, size_t limit, uint64_t *scratch,
+                         uint32_t *dst);
 // suffix_array.hip: d_sa_out may alias nothing in the workspace; d_text is caller or ctx owned
 int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_sa_out);
 // bwt.hip

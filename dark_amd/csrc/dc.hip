@@ -151,9 +151,17 @@ __global__ __launch_bounds__(256) void k_dc_carry_c(uint32_t *__restrict__ tile_
     }
 }
 
-// LDS layout of a wave's 256-entry table: symbol c lives at word ((c & 63) << 2) | (c >> 6), so that lane l owns the four
-// consecutive words of symbols l, l+64, l+128, l+192 (one 16-byte read) and a single symbol is one broadcast read.
+// LDS layout of a wave's tables.  s_pos (u32[256], the vector side): symbol c lives at word ((c & 63) << 2) | (c >> 6), so
+// that lane l owns the four consecutive words of symbols l, l+64, l+128, l+192 (one 16-byte read).  s_pr (uint2[256], the
+// scalar side): {last position + 1, run index + 1} of symbol c at index c (one 8-byte broadcast read / store).
 __device__ __forceinline__ uint32_t tab_index(uint32_t c) { return ((c & 63u) << 2) | (c >> 6); }
+
+// v_writelane_b32: lane `sel` of `old` becomes the (wave-uniform) value; all three operands of the write are scalar
+__device__ __forceinline__ uint32_t write_lane(uint32_t value, int sel, uint32_t old) {
+    // gfx9 lets a VALU instruction read one SGPR only; the lane select goes through M0, which does not count
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(value), "s"(sel) : "m0");
+    return old;
+}
 
 __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict__ L, size_t n, size_t ntiles,
                                                        const uint32_t *__restrict__ carry_last, const uint32_t *__restrict__ carry_lrun,
@@ -162,19 +170,21 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
                                                        uint32_t *__restrict__ init, uint32_t *__restrict__ final_last,
                                                        uint32_t *__restrict__ final_lrun) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[DC_WAVES][DC_PAD + DC_TILE + 16];
-    __shared__ __attribute__((aligned(16))) uint32_t s_pos[DC_WAVES][256];  // last position + 1 of every symbol (0 = not seen yet)
-    __shared__ __attribute__((aligned(16))) uint32_t s_run[DC_WAVES][256];  // run index + 1 of that occurrence
+    __shared__ __attribute__((aligned(16))) uint32_t s_pos[DC_WAVES][256];
+    __shared__ __attribute__((aligned(16))) uint2 s_pr[DC_WAVES][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t tile = static_cast<size_t>(blockIdx.x) * DC_WAVES + wave;
     if (tile >= ntiles) return;
     const size_t base = tile * DC_TILE;
     uint8_t *s = s_tile[wave];
-    uint32_t *pos = s_pos[wave], *run = s_run[wave];
+    uint32_t *pos = s_pos[wave];
+    uint2 *pr = s_pr[wave];
     stage_tile(L, n, base, s, lane);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        pos[(lane << 2) | k] = carry_last[tile * 256 + k * 64 + lane];
-        run[(lane << 2) | k] = carry_lrun[tile * 256 + k * 64 + lane];
+        const uint32_t cp = carry_last[tile * 256 + k * 64 + lane], cr = carry_lrun[tile * 256 + k * 64 + lane];
+        pos[(lane << 2) | k] = cp;
+        pr[k * 64 + lane] = make_uint2(cp, cr);
     }
     // wave-uniform values are pinned to scalar registers: the per-run loop below is scalar control flow
     uint32_t r = __builtin_amdgcn_readfirstlane(tile_run_base[tile]);  // index of the next run to start
@@ -188,46 +198,59 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
         const uint32_t pc = s[DC_PAD + j - 1];
         const bool start = p < n && (p == 0 || c != pc);
         uint64_t m = __ballot(start);
-        while (m) {
+        if (m == 0) continue;
+        // Results of this chunk's runs are gathered lane by lane (v_writelane) and leave as ONE vector store per array:
+        // lane k ends up holding the k-th run of the chunk.
+        const uint32_t r0 = r;
+        uint32_t o_sym = 0, o_rank = 0, o_didx = 0xFFFFFFFFu, o_dval = 0, o_end = 0;
+        int k = 0;
+        do {
             const int bit = __builtin_ctzll(m);
             m &= m - 1;
             const uint32_t i = base32 + static_cast<uint32_t>(chunk * 64 + bit);
             const uint32_t cs = __builtin_amdgcn_readlane(c, bit);
             const uint32_t ps = __builtin_amdgcn_readlane(pc, bit);
-            if (i > 0) {  // the run of `ps` ended at i-1; it is run r-1.  Every lane stores the same word: no divergence.
+            if (i > 0 && lane == 0) {  // the run of `ps` ended at i-1; it is run r-1
                 pos[tab_index(ps)] = i;
-                run[tab_index(ps)] = r;
-                if (run_end && lane == 0) run_end[r - 1] = i - 1;
+                pr[ps] = make_uint2(i, r);
             }
             __builtin_amdgcn_wave_barrier();
-            const uint32_t b1 = __builtin_amdgcn_readfirstlane(pos[tab_index(cs)]);
-            const uint32_t rb1 = __builtin_amdgcn_readfirstlane(run[tab_index(cs)]);
+            const uint2 prev = pr[cs];  // broadcast read; cs != ps, so the stores above do not touch it
             const uint4 mine = *reinterpret_cast<const uint4 *>(pos + (lane << 2));
-            uint32_t cnt = 0;
-            if (b1) {  // rank = number of symbols seen since the previous occurrence of cs
-                cnt = static_cast<uint32_t>(__popcll(__ballot(mine.x > b1)) + __popcll(__ballot(mine.y > b1)) +
-                                            __popcll(__ballot(mine.z > b1)) + __popcll(__ballot(mine.w > b1)));
-            }
-            if (lane == 0) {
-                if (b1) dist[rb1 - 1] = i - b1 - cnt;  // = i - b - rank - 1 with b = b1 - 1
-                else init[cs] = i;
-                sym[r] = static_cast<uint8_t>(cs);
-                if (rank) rank[r] = static_cast<uint8_t>(cnt);
-            }
+            const uint32_t b1 = __builtin_amdgcn_readfirstlane(prev.x);
+            const uint32_t rb1 = __builtin_amdgcn_readfirstlane(prev.y);
+            // rank = number of symbols seen since the previous occurrence of cs (0 for a first occurrence: every entry > 0 = b1
+            // would count, so mask it out)
+            uint32_t cnt = static_cast<uint32_t>(__popcll(__ballot(mine.x > b1)) + __popcll(__ballot(mine.y > b1)) +
+                                                 __popcll(__ballot(mine.z > b1)) + __popcll(__ballot(mine.w > b1)));
+            cnt = b1 ? cnt : 0u;
+            if (b1 == 0 && lane == 0) init[cs] = i;  // first occurrence (at most 256 times per block)
+            o_sym = write_lane(cs, k, o_sym);
+            o_rank = write_lane(cnt, k, o_rank);
+            o_didx = write_lane(b1 ? rb1 - 1 : 0xFFFFFFFFu, k, o_didx);
+            o_dval = write_lane(i - b1 - cnt, k, o_dval);  // = i - b - rank - 1 with b = b1 - 1
+            o_end = write_lane(i - 1, k, o_end);            // end of the previous run (run r-1), i > 0
             ++r;
+            ++k;
+        } while (m);
+        if (lane < k) {
+            sym[r0 + lane] = static_cast<uint8_t>(o_sym);
+            if (rank) rank[r0 + lane] = static_cast<uint8_t>(o_rank);
+            if (o_didx != 0xFFFFFFFFu) dist[o_didx] = o_dval;
+            if (run_end && r0 + lane > 0) run_end[r0 + lane - 1] = o_end;
         }
     }
     if (tile == ntiles - 1) {  // close the last run of the block and publish the final table for the sweep
         const uint32_t ps = L[n - 1];
         pos[tab_index(ps)] = static_cast<uint32_t>(n);
-        run[tab_index(ps)] = r;
+        pr[ps] = make_uint2(static_cast<uint32_t>(n), r);
         if (run_end && lane == 0) run_end[r - 1] = static_cast<uint32_t>(n - 1);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            final_last[k * 64 + lane] = pos[(lane << 2) | k];
-            final_lrun[k * 64 + lane] = run[(lane << 2) | k];
+            final_last[k * 64 + lane] = pr[k * 64 + lane].x;
+            final_lrun[k * 64 + lane] = pr[k * 64 + lane].y;
         }
     }
 }

@@ -28,7 +28,17 @@ constexpr int RS_MAX_CHUNKS = 256;
 
 __device__ __forceinline__ uint32_t digit_of(uint64_t k, int shift) { return static_cast<uint32_t>(k >> shift) & 0xFFu; }
 
-__global__ __launch_bounds__(RS_BLOCK) void k_radix_hist(const uint64_t *__restrict__ keys, size_t n, int shift,
+// PAIRS = true: the key of element i is (hi[i] << 32) | lo[i], read from two u32 arrays, and there is no value array
+template <bool PAIRS>
+__device__ __forceinline__ uint64_t load_key(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ hi,
+                                             const uint32_t *__restrict__ lo, size_t i) {
+    if (PAIRS) return (static_cast<uint64_t>(hi[i]) << 32) | lo[i];
+    return keys[i];
+}
+
+template <bool PAIRS>
+__global__ __launch_bounds__(RS_BLOCK) void k_radix_hist(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ hi,
+                                                          const uint32_t *__restrict__ lo, size_t n, int shift,
                                                           uint32_t *__restrict__ tile_hist) {
     __shared__ uint32_t h[256];
     const int tid = threadIdx.x;
@@ -38,7 +48,7 @@ __global__ __launch_bounds__(RS_BLOCK) void k_radix_hist(const uint64_t *__restr
 #pragma unroll
     for (int k = 0; k < RS_KPT; ++k) {
         const size_t i = base + static_cast<size_t>(k) * RS_BLOCK + tid;
-        if (i < n) atomicAdd(&h[digit_of(keys[i], shift)], 1u);
+        if (i < n) atomicAdd(&h[digit_of(load_key<PAIRS>(keys, hi, lo, i), shift)], 1u);
     }
     __syncthreads();
     tile_hist[static_cast<size_t>(blockIdx.x) * 256 + tid] = h[tid];
@@ -136,8 +146,9 @@ constexpr uint32_t RS_SPIN_LIMIT = 1u << 22;
 // LOOKBACK = false: tile = blockIdx.x, offsets come from the scanned tile_offs table.
 // LOOKBACK = true : tile = atomic ticket, `tile_offs` is the status array [ntiles][256] (zeroed), `digit_base` the
 //                   exclusive digit starts of this pass, ctrl[0] the ticket counter, ctrl[1] the error word.
-template <bool LOOKBACK>
+template <bool LOOKBACK, bool PAIRS = false>
 __global__ __launch_bounds__(RS_BLOCK) void k_radix_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                             const uint32_t *__restrict__ pair_lo,
                                                              uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n,
                                                              int shift, uint32_t *__restrict__ tile_offs,
                                                              const uint32_t *__restrict__ digit_base, uint32_t *__restrict__ ctrl,
@@ -179,8 +190,8 @@ __global__ __launch_bounds__(RS_BLOCK) void k_radix_scatter(const uint64_t *__re
     for (int k = 0; k < RS_KPT; ++k) {
         const uint32_t li = wbase + k * 64 + lane;
         if (li < valid) {
-            key[k] = kin[tile_base + li];
-            val[k] = vin[tile_base + li];
+            key[k] = load_key<PAIRS>(kin, vin, pair_lo, tile_base + li);  // PAIRS: vin holds the high words
+            val[k] = PAIRS ? 0u : vin[tile_base + li];
             if (LOOKBACK) atomicAdd(&s_hist[digit_of(key[k], shift)], 1u);
         } else {
             key[k] = ~0ull;  // padding sorts behind every real pair of the tile and is never written
@@ -275,6 +286,7 @@ __global__ __launch_bounds__(RS_BLOCK) void k_radix_scatter(const uint64_t *__re
         gi[k] = s_gbase[digit_of(kk, shift)] + p;
         if (p < valid) kout[gi[k]] = kk;
     }
+    if (PAIRS) return;  // keys only
     __syncthreads();
     uint32_t *s_vals = reinterpret_cast<uint32_t *>(s_keys);
 #pragma unroll
@@ -304,7 +316,7 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
     for (int shift = begin_bit; shift < end_bit; shift += 8) {
         {
             LaunchScope ls(ctx, K_RADIX_HIST, 8.0 * count);
-            k_radix_hist<<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(keys, count, shift, tile_hist);
+            k_radix_hist<false><<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(keys, nullptr, nullptr, count, shift, tile_hist);
         }
         {
             LaunchScope ls(ctx, K_RADIX_SCAN, 3.0 * 1024.0 * ntiles);
@@ -316,7 +328,7 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
             LaunchScope ls(ctx, K_RADIX_SCATTER, 24.0 * count);
             static const bool xcd = [] { const char *e = getenv("DK_XCD"); return !(e && e[0] == '0'); }();
             const size_t grid = xcd ? 8 * div_up(ntiles, 8) : ntiles;
-            k_radix_scatter<false><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(keys, vals, keys_alt, vals_alt, count, shift, tile_hist,
+            k_radix_scatter<false><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(keys, vals, nullptr, keys_alt, vals_alt, count, shift, tile_hist,
                                                                          nullptr, nullptr, xcd ? static_cast<uint32_t>(ntiles) : 0u);
         }
         DK_HIP(ctx, hipGetLastError());
@@ -352,7 +364,7 @@ static int sort_pairs_onesweep(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt
         DK_HIP(ctx, hipMemsetAsync(ctrl, 0, (64 + ntiles * 256) * sizeof(uint32_t), st));
         {
             LaunchScope ls(ctx, K_RADIX_SCATTER, 24.0 * count);
-            k_radix_scatter<true><<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(keys, vals, keys_alt, vals_alt, count, begin_bit + 8 * p,
+            k_radix_scatter<true><<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(keys, vals, nullptr, keys_alt, vals_alt, count, begin_bit + 8 * p,
                                                                           status, digit_base + p * 256, ctrl, 0u);
         }
         DK_HIP(ctx, hipGetLastError());
@@ -376,6 +388,69 @@ int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&val
     static const bool onesweep = [] { const char *e = getenv("DK_SORT"); return e && std::string(e) == "onesweep"; }();
     if (!onesweep || count >= (1ull << 30)) return sort_pairs_classic(ctx, keys, keys_alt, vals, vals_alt, count, begin_bit, end_bit);
     return sort_pairs_onesweep(ctx, keys, keys_alt, vals, vals_alt, count, begin_bit, end_bit);
+}
+
+// ---- bucketed scatter: dst[idx[i]] = val[i] for a huge, random idx ---------------------------------------------------
+// A random 4-byte store costs a whole 64-byte line at the HBM (read-modify-write).  Partition the (idx, val) pairs by the
+// top 8 bits of idx first (one stable radix pass over pairs, 16 B/pair), then store bucket by bucket: a bucket's
+// destinations span n/256 words (1.5 MiB at n = 1e8), the XCD-aware tile order keeps one bucket on one XCD, and its lines
+// are completed in that XCD's L2 before they are written back.
+__global__ __launch_bounds__(RS_BLOCK) void k_bucket_store(const uint64_t *__restrict__ pairs, size_t n, uint32_t ntiles,
+                                                            uint32_t *__restrict__ dst) {
+    const uint32_t per = gridDim.x / 8;
+    const uint32_t tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (tile >= ntiles) return;
+    const size_t base = static_cast<size_t>(tile) * RS_TILE;
+#pragma unroll
+    for (int k = 0; k < RS_KPT; ++k) {
+        const size_t i = base + static_cast<size_t>(k) * RS_BLOCK + threadIdx.x;
+        if (i < n) {
+            const uint64_t p = __builtin_nontemporal_load(pairs + i);  // streamed once: keep it out of the way of the destination lines
+            dst[static_cast<uint32_t>(p >> 32)] = static_cast<uint32_t>(p);
+        }
+    }
+}
+
+// dst[idx[i]] = val[i], i < count; idx values are distinct and < limit.  `scratch` holds count u64.
+int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, size_t count, size_t limit, uint64_t *scratch,
+                         uint32_t *dst) {
+    if (count == 0) return DK_OK;
+    const size_t ntiles = div_up(count, RS_TILE);
+    const size_t tiles_per_chunk = div_up(ntiles, RS_MAX_CHUNKS);
+    const size_t nchunks = div_up(ntiles, tiles_per_chunk);
+    const size_t mark = ctx->ws_mark();
+    uint32_t *tile_hist = ctx->ws_alloc<uint32_t>(ntiles * 256);
+    uint32_t *chunk_sum = ctx->ws_alloc<uint32_t>(nchunks * 256);
+    if (!tile_hist || !chunk_sum) return DK_E_NOMEM;
+    hipStream_t st = ctx->stream;
+    const unsigned lb = ceil_log2_u64(limit);
+    const int shift = 32 + static_cast<int>(lb > 8 ? lb - 8 : 0);
+    const size_t grid = 8 * div_up(ntiles, 8);
+    {
+        LaunchScope ls(ctx, K_RADIX_HIST, 8.0 * count);
+        k_radix_hist<true><<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(nullptr, idx, val, count, shift, tile_hist);
+    }
+    {
+        LaunchScope ls(ctx, K_RADIX_SCAN, 3.0 * 1024.0 * ntiles);
+        k_radix_scan_a<<<dim3(nchunks), dim3(256), 0, st>>>(tile_hist, ntiles, tiles_per_chunk, chunk_sum);
+        k_radix_scan_b<<<dim3(1), dim3(1024), 0, st>>>(chunk_sum, nchunks);
+        k_radix_scan_c<<<dim3(nchunks), dim3(256), 0, st>>>(tile_hist, ntiles, tiles_per_chunk, chunk_sum);
+    }
+    {
+        LaunchScope ls(ctx, K_RADIX_SCATTER, 16.0 * count);
+        k_radix_scatter<false, true><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(nullptr, idx, val, scratch, nullptr, count, shift, tile_hist,
+                                                                              nullptr, nullptr, static_cast<uint32_t>(ntiles));
+    }
+    {
+        LaunchScope ls(ctx, K_MISC, 12.0 * count);
+        // 72 KiB of (unused) dynamic LDS caps residency at 2 workgroups per CU: ~260 K pairs in flight per XCD, less than one
+        // bucket, so the lines of the bucket being written stay in that XCD's 4 MiB L2 until they are complete
+        static const size_t lds_cap = [] { const char *e = getenv("DK_BUCKET_LDS"); return e ? static_cast<size_t>(atoi(e)) : size_t(72 * 1024); }();
+        k_bucket_store<<<dim3(grid), dim3(RS_BLOCK), lds_cap, st>>>(scratch, count, static_cast<uint32_t>(ntiles), dst);
+    }
+    DK_HIP(ctx, hipGetLastError());
+    ctx->ws_release(mark);
+    return DK_OK;
 }
 
 // error word of the look-back path (non-zero: a spin hit its bound); resets it

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
                                                             const RerankAgg *__restrict__ agg, uint32_t *__restrict__ rank,
                                                             uint32_t *__restrict__ sa, uint32_t *__restrict__ out_idx,
                                                             uint32_t *__restrict__ out_pos, uint32_t *__restrict__ out_gid,
-                                                            uint32_t *__restrict__ gstart) {
+                                                            uint32_t *__restrict__ gstart, uint32_t *__restrict__ headpos_out) {
     __shared__ uint32_t s_tmp[RR_WAVES + 1];
     const size_t a0 = static_cast<size_t>(blockIdx.x) * RR_TILE + static_cast<size_t>(threadIdx.x) * RR_IPT;
     bool head[RR_IPT], surv[RR_IPT], oldh[RR_IPT];
@@ -175,7 +175,8 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
         const uint32_t suffix = idx[a];
         const uint32_t my_pos = pos_in ? pos_in[a] : static_cast<uint32_t>(a);
         // members of a new group whose head already headed the old group keep their rank: no scatter
-        if (!(el & 1u)) rank[suffix] = pos_in ? pos_in[el >> 1] : (el >> 1);
+        if (headpos_out) headpos_out[a] = el >> 1;  // first rerank of a large block: ranks are stored by the bucketed scatter
+        else if (!(el & 1u)) rank[suffix] = pos_in ? pos_in[el >> 1] : (el >> 1);
         if (!surv[j]) {
             sa[my_pos] = suffix;  // the group is a singleton: this suffix is in its final place
         } else {
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
 }
 
 int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_t *pos_in, size_t count, int gshift, uint32_t *rank,
-           uint32_t *sa, uint32_t *out_idx, uint32_t *out_pos, uint32_t *out_gid, uint32_t *gstart) {
+           uint32_t *sa, uint32_t *out_idx, uint32_t *out_pos, uint32_t *out_gid, uint32_t *gstart, uint32_t *headpos_out = nullptr) {
     const size_t ntiles = div_up(count, RR_TILE);
     const size_t mark = ctx->ws_mark();
     RerankAgg *agg = ctx->ws_alloc<RerankAgg>(ntiles);
@@ -205,7 +206,7 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
     }
     {
         LaunchScope ls(ctx, K_RERANK_APPLY, 8.0 * count + 4.0 * count + 4.0 * count + 12.0 * count);
-        k_rerank_apply<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gshift, agg, rank, sa, out_idx, out_pos, out_gid, gstart);
+        k_rerank_apply<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gshift, agg, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out);
     }
     DK_HIP(ctx, hipGetLastError());
     ctx->ws_release(mark);
@@ -436,7 +437,15 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
 
     // 4. first rerank (slots are SA positions)
     size_t active = 0, groups = 0, nbig = 0;
-    DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, rank, d_sa, vals_alt, pos, gid, gstart));
+    static const bool bucketed = [] { const char *e = getenv("DK_BUCKETED"); return !(e && e[0] == '0'); }();
+    if (bucketed && n >= (1u << 22)) {
+        // rank[suffix] = head position for all n suffixes: too random for plain stores (every 4-byte store is a 64-byte line
+        // at the HBM) -> the rerank only lists the head positions, the bucketed scatter stores them XCD-locally
+        DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, rank, d_sa, vals_alt, pos, gid, gstart, vals_3));
+        DK_TRY(scatter_u32_bucketed(ctx, vals, vals_3, n, n, keys_alt, rank));
+    } else {
+        DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, rank, d_sa, vals_alt, pos, gid, gstart));
+    }
     DK_TRY(classify_and_read(ctx, n / 2, gstart, bigstart, &active, &groups, &nbig));
     std::swap(vals, vals_alt);  // vals = suffix indices of the active list
 
