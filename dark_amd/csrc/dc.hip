@@ -156,11 +156,22 @@ __global__ __launch_bounds__(256) void k_dc_carry_c(uint32_t *__restrict__ tile_
 // scalar side): {last position + 1, run index + 1} of symbol c at index c (one 8-byte broadcast read / store).
 __device__ __forceinline__ uint32_t tab_index(uint32_t c) { return ((c & 63u) << 2) | (c >> 6); }
 
-// v_writelane_b32: lane `sel` of `old` becomes the (wave-uniform) value; all three operands of the write are scalar
-__device__ __forceinline__ uint32_t write_lane(uint32_t value, int sel, uint32_t old) {
-    // gfx9 lets a VALU instruction read one SGPR only; the lane select goes through M0, which does not count
-    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(value), "s"(sel) : "m0");
-    return old;
+// Five v_writelane_b32 at once: lane `sel` of every o* becomes the matching (wave-uniform) value.  gfx9 lets a VALU instruction
+// read one SGPR only, so the lane select goes through M0 (which does not count); M0 is saved and restored around the group.
+__device__ __forceinline__ void write_lane5(int sel, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t v4, uint32_t &o0,
+                                            uint32_t &o1, uint32_t &o2, uint32_t &o3, uint32_t &o4) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %5, m0\n\t"
+        "s_mov_b32 m0, %6\n\t"
+        "v_writelane_b32 %0, %7, m0\n\t"
+        "v_writelane_b32 %1, %8, m0\n\t"
+        "v_writelane_b32 %2, %9, m0\n\t"
+        "v_writelane_b32 %3, %10, m0\n\t"
+        "v_writelane_b32 %4, %11, m0\n\t"
+        "s_mov_b32 m0, %5"
+        : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3), "+v"(o4), "=&s"(keep)
+        : "s"(sel), "s"(v0), "s"(v1), "s"(v2), "s"(v3), "s"(v4));
 }
 
 __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict__ L, size_t n, size_t ntiles,
@@ -225,11 +236,8 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
                                                  __popcll(__ballot(mine.z > b1)) + __popcll(__ballot(mine.w > b1)));
             cnt = b1 ? cnt : 0u;
             if (b1 == 0 && lane == 0) init[cs] = i;  // first occurrence (at most 256 times per block)
-            o_sym = write_lane(cs, k, o_sym);
-            o_rank = write_lane(cnt, k, o_rank);
-            o_didx = write_lane(b1 ? rb1 - 1 : 0xFFFFFFFFu, k, o_didx);
-            o_dval = write_lane(i - b1 - cnt, k, o_dval);  // = i - b - rank - 1 with b = b1 - 1
-            o_end = write_lane(i - 1, k, o_end);            // end of the previous run (run r-1), i > 0
+            // dval = i - b - rank - 1 with b = b1 - 1; o_end = end of the previous run (run r-1)
+            write_lane5(k, cs, cnt, b1 ? rb1 - 1 : 0xFFFFFFFFu, i - b1 - cnt, i - 1, o_sym, o_rank, o_didx, o_dval, o_end);
             ++r;
             ++k;
         } while (m);

@@ -58,46 +58,61 @@ __global__ __launch_bounds__(256) void k_sa_descending(uint32_t *__restrict__ sa
 // ---- rerank: three kernels sharing the per-slot flag logic ------------------------------------------------------
 struct RerankAgg { uint32_t surv, heads, last_head, pad; };
 
-// flags of the RR_IPT slots starting at a0: head[j] = key differs from its predecessor (slot 0 is a head);
-// surv[j] = the slot's group has more than one member
-// oldh[j] = the slot is a head AND was already the head of its group before this round (gshift >= 0: the group id sits
-// above bit gshift of the key): members of such a new group keep their rank, so the rank scatter can be skipped.
-__device__ __forceinline__ void slot_flags(const uint64_t *__restrict__ keys, size_t count, size_t a0, int gshift, bool head[RR_IPT],
-                                           bool surv[RR_IPT], bool oldh[RR_IPT]) {
-    uint64_t k[RR_IPT + 2];
-#pragma unroll
-    for (int j = 0; j < RR_IPT + 2; ++j) {
-        const size_t a = a0 + j;  // k[j] = key of slot a0 + j - 1
-        k[j] = (a >= 1 && a - 1 < count) ? keys[a - 1] : 0;
+// Per-slot flags, computed with lane-contiguous (coalesced) accesses and parked in LDS as one byte per slot:
+//   bit 0 head : the key differs from its predecessor (slot 0 is a head)
+//   bit 1 surv : the slot's group has more than one member
+//   bit 2 oldh : the slot is a head AND already headed its group before this round (gshift >= 0: the group id sits above
+//                bit gshift of the key); members of such a group keep their rank, so the rank scatter is skipped
+constexpr uint32_t F_HEAD = 1, F_SURV = 2, F_OLDH = 4;
+
+__device__ __forceinline__ uint32_t slot_flag_bits(uint64_t prev, uint64_t cur, uint64_t next, size_t a, size_t count, int gshift) {
+    if (a >= count) return 0;
+    const bool head = a == 0 || cur != prev;
+    const bool next_head = a + 1 >= count || next != cur;
+    const bool oldh = head && gshift >= 0 && (a == 0 || (cur >> gshift) != (prev >> gshift));
+    return (head ? F_HEAD : 0u) | (!(head && next_head) ? F_SURV : 0u) | (oldh ? F_OLDH : 0u);
+}
+
+// stage keys[b0-1 .. b0+RR_TILE] into s_key[0 .. RR_TILE+1] (coalesced), then the flag bytes of the tile into s_flag
+__device__ __forceinline__ void stage_flags(const uint64_t *__restrict__ keys, size_t count, size_t b0, int gshift,
+                                            uint64_t *s_key, uint8_t *s_flag) {
+    const int tid = threadIdx.x;
+    for (int o = tid; o < RR_TILE + 2; o += RR_BLOCK) {
+        const size_t a = b0 + o;  // slot a - 1
+        s_key[o] = (a >= 1 && a - 1 < count) ? keys[a - 1] : 0;
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RR_IPT; ++k) {
+        const int o = k * RR_BLOCK + tid;
+        s_flag[o] = static_cast<uint8_t>(slot_flag_bits(s_key[o], s_key[o + 1], s_key[o + 2], b0 + o, count, gshift));
+    }
+    __syncthreads();
+}
+
+// the RR_IPT consecutive slots of this thread: counts and the last head, encoded (slot << 1) | old_head so that one
+// max-scan carries both
+__device__ __forceinline__ void thread_summary(uint64_t fl, size_t a0, uint32_t &ns, uint32_t &nh, uint32_t &lh) {
+    ns = nh = lh = 0;
 #pragma unroll
     for (int j = 0; j < RR_IPT; ++j) {
-        const size_t a = a0 + j;
-        head[j] = a < count && (a == 0 || k[j + 1] != k[j]);
-        oldh[j] = head[j] && gshift >= 0 && (a == 0 || (k[j + 1] >> gshift) != (k[j] >> gshift));
-    }
-#pragma unroll
-    for (int j = 0; j < RR_IPT; ++j) {
-        const size_t a = a0 + j;
-        const bool next_head = (a + 1 >= count) || (k[j + 2] != k[j + 1]);
-        surv[j] = a < count && !(head[j] && next_head);
+        const uint32_t f = static_cast<uint32_t>(fl >> (8 * j)) & 0xFFu;
+        ns += (f & F_SURV) ? 1u : 0u;
+        nh += ((f & F_HEAD) && (f & F_SURV)) ? 1u : 0u;
+        if (f & F_HEAD) lh = (static_cast<uint32_t>(a0 + j) << 1) | ((f & F_OLDH) ? 1u : 0u);
     }
 }
 
-// last_head values travel as (slot << 1) | old_head so that one max-scan carries both
 __global__ __launch_bounds__(RR_BLOCK) void k_rerank_reduce(const uint64_t *__restrict__ keys, size_t count, int gshift,
                                                              RerankAgg *__restrict__ agg) {
+    __shared__ uint64_t s_key[RR_TILE + 2];
+    __shared__ __attribute__((aligned(8))) uint8_t s_flag[RR_TILE];
     __shared__ uint32_t s_red[3][RR_WAVES];
-    const size_t a0 = static_cast<size_t>(blockIdx.x) * RR_TILE + static_cast<size_t>(threadIdx.x) * RR_IPT;
-    bool head[RR_IPT], surv[RR_IPT], oldh[RR_IPT];
-    slot_flags(keys, count, a0, gshift, head, surv, oldh);
-    uint32_t ns = 0, nh = 0, lh = 0;
-#pragma unroll
-    for (int j = 0; j < RR_IPT; ++j) {
-        ns += surv[j];
-        nh += head[j] && surv[j];
-        if (head[j]) lh = (static_cast<uint32_t>(a0 + j) << 1) | (oldh[j] ? 1u : 0u);
-    }
+    const size_t b0 = static_cast<size_t>(blockIdx.x) * RR_TILE;
+    stage_flags(keys, count, b0, gshift, s_key, s_flag);
+    const size_t a0 = b0 + static_cast<size_t>(threadIdx.x) * RR_IPT;
+    uint32_t ns, nh, lh;
+    thread_summary(*reinterpret_cast<const uint64_t *>(s_flag + threadIdx.x * RR_IPT), a0, ns, nh, lh);
     ns = wave_sum(ns);
     nh = wave_sum(nh);
     lh = wave_max(lh);
@@ -144,48 +159,78 @@ __global__ __launch_bounds__(1024) void k_rerank_scan(RerankAgg *__restrict__ ag
     if (tid == 0) { mail[0] = tot_s; mail[1] = tot_h; gstart[tot_h] = tot_s; }  // sentinel: one past the last group
 }
 
-// pos_in == nullptr means slot a sits at SA position a (first rerank, straight after the initial sort)
+// pos_in == nullptr means slot a sits at SA position a (first rerank, straight after the initial sort).
+// All tile inputs arrive through LDS with lane-contiguous loads; the compacted outputs leave through LDS the same way.
 __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx,
                                                             const uint32_t *__restrict__ pos_in, size_t count, int gshift,
                                                             const RerankAgg *__restrict__ agg, uint32_t *__restrict__ rank,
                                                             uint32_t *__restrict__ sa, uint32_t *__restrict__ out_idx,
                                                             uint32_t *__restrict__ out_pos, uint32_t *__restrict__ out_gid,
                                                             uint32_t *__restrict__ gstart, uint32_t *__restrict__ headpos_out) {
+    __shared__ uint64_t s_key[RR_TILE + 2];                       // later reused: compacted idx | pos
+    __shared__ __attribute__((aligned(16))) uint32_t s_idx[RR_TILE];
+    __shared__ __attribute__((aligned(16))) uint32_t s_pos[RR_TILE];
+    __shared__ uint32_t s_ogid[RR_TILE];
+    __shared__ __attribute__((aligned(8))) uint8_t s_flag[RR_TILE];
     __shared__ uint32_t s_tmp[RR_WAVES + 1];
-    const size_t a0 = static_cast<size_t>(blockIdx.x) * RR_TILE + static_cast<size_t>(threadIdx.x) * RR_IPT;
-    bool head[RR_IPT], surv[RR_IPT], oldh[RR_IPT];
-    slot_flags(keys, count, a0, gshift, head, surv, oldh);
-    uint32_t ns = 0, nh = 0, lh = 0;
+    const int tid = threadIdx.x;
+    const size_t b0 = static_cast<size_t>(blockIdx.x) * RR_TILE;
 #pragma unroll
-    for (int j = 0; j < RR_IPT; ++j) {
-        ns += surv[j];
-        nh += head[j] && surv[j];
-        if (head[j]) lh = (static_cast<uint32_t>(a0 + j) << 1) | (oldh[j] ? 1u : 0u);
+    for (int k = 0; k < RR_IPT; ++k) {
+        const int o = k * RR_BLOCK + tid;
+        const size_t a = b0 + o;
+        if (a < count) {
+            s_idx[o] = idx[a];
+            s_pos[o] = pos_in ? pos_in[a] : static_cast<uint32_t>(a);
+        }
     }
+    stage_flags(keys, count, b0, gshift, s_key, s_flag);  // ends with a barrier: s_idx / s_pos are visible, s_key is free
+    const size_t a0 = b0 + static_cast<size_t>(tid) * RR_IPT;
+    const uint64_t fl = *reinterpret_cast<const uint64_t *>(s_flag + tid * RR_IPT);
+    uint32_t ns, nh, lh;
+    thread_summary(fl, a0, ns, nh, lh);
     const RerankAgg base = agg[blockIdx.x];
-    uint32_t es = base.surv + block_excl_sum<RR_WAVES>(ns, s_tmp, nullptr);
+    uint32_t block_surv;
+    uint32_t es = block_excl_sum<RR_WAVES>(ns, s_tmp, &block_surv);  // tile-local compaction offset
     uint32_t eh = base.heads + block_excl_sum<RR_WAVES>(nh, s_tmp, nullptr);
     uint32_t el = block_excl_max<RR_WAVES>(lh, s_tmp, nullptr);
     el = el > base.last_head ? el : base.last_head;
+    uint32_t *s_oidx = reinterpret_cast<uint32_t *>(s_key);
+    uint32_t *s_opos = s_oidx + RR_TILE;
+    uint32_t my_idx[RR_IPT], my_pos[RR_IPT];
+    {
+        const uint4 *pi = reinterpret_cast<const uint4 *>(s_idx + tid * RR_IPT), *pp = reinterpret_cast<const uint4 *>(s_pos + tid * RR_IPT);
+        const uint4 i0 = pi[0], i1 = pi[1], p0 = pp[0], p1 = pp[1];
+        my_idx[0] = i0.x; my_idx[1] = i0.y; my_idx[2] = i0.z; my_idx[3] = i0.w; my_idx[4] = i1.x; my_idx[5] = i1.y; my_idx[6] = i1.z; my_idx[7] = i1.w;
+        my_pos[0] = p0.x; my_pos[1] = p0.y; my_pos[2] = p0.z; my_pos[3] = p0.w; my_pos[4] = p1.x; my_pos[5] = p1.y; my_pos[6] = p1.z; my_pos[7] = p1.w;
+    }
 #pragma unroll
     for (int j = 0; j < RR_IPT; ++j) {
         const size_t a = a0 + j;
         if (a >= count) break;
-        if (head[j]) el = (static_cast<uint32_t>(a) << 1) | (oldh[j] ? 1u : 0u);
-        const uint32_t suffix = idx[a];
-        const uint32_t my_pos = pos_in ? pos_in[a] : static_cast<uint32_t>(a);
-        // members of a new group whose head already headed the old group keep their rank: no scatter
-        if (headpos_out) headpos_out[a] = el >> 1;  // first rerank of a large block: ranks are stored by the bucketed scatter
-        else if (!(el & 1u)) rank[suffix] = pos_in ? pos_in[el >> 1] : (el >> 1);
-        if (!surv[j]) {
-            sa[my_pos] = suffix;  // the group is a singleton: this suffix is in its final place
+        const uint32_t f = static_cast<uint32_t>(fl >> (8 * j)) & 0xFFu;
+        if (f & F_HEAD) el = (static_cast<uint32_t>(a) << 1) | ((f & F_OLDH) ? 1u : 0u);
+        const uint32_t suffix = my_idx[j];
+        // SA position of the group's head: the head slot is in this tile (LDS) or in an earlier one (global, rare)
+        const size_t hs = el >> 1;
+        const uint32_t head_pos = !pos_in ? static_cast<uint32_t>(hs) : (hs >= b0 ? s_pos[hs - b0] : pos_in[hs]);
+        if (headpos_out) headpos_out[a] = head_pos;  // first rerank of a large block: ranks are stored by the bucketed scatter
+        else if (!(el & 1u)) rank[suffix] = head_pos;  // members of a group that kept its head keep their rank: no scatter
+        if (!(f & F_SURV)) {
+            sa[my_pos[j]] = suffix;  // the group is a singleton: this suffix is in its final place
         } else {
-            if (head[j]) { gstart[eh] = es; ++eh; }  // first slot of the surviving group in the new active list
-            out_idx[es] = suffix;
-            out_pos[es] = my_pos;
-            out_gid[es] = eh - 1;
+            if (f & F_HEAD) { gstart[eh] = base.surv + es; ++eh; }  // first slot of the surviving group in the new active list
+            s_oidx[es] = suffix;
+            s_opos[es] = my_pos[j];
+            s_ogid[es] = eh - 1;
             ++es;
         }
+    }
+    __syncthreads();
+    for (uint32_t o = tid; o < block_surv; o += RR_BLOCK) {
+        out_idx[base.surv + o] = s_oidx[o];
+        out_pos[base.surv + o] = s_opos[o];
+        out_gid[base.surv + o] = s_ogid[o];
     }
 }
 
