@@ -161,13 +161,23 @@ def main():
         kern = stats["kernels"]
         dom_name = max(kern, key=lambda kk: kern[kk]["ms"]) if kern else None
         roofline = None
+        pmc = None
+        try:  # HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (same command, same workload)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_enwik8like_1e8.json")) as f:
+                pmc = json.load(f)
+        except OSError:
+            pass
         if dom_name:
             dk_ = kern[dom_name]
             achieved = dk_["bytes"] / (dk_["ms"] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                         "launches": dk_["launches"], "avg_launch_us": round(1e3 * dk_["ms"] / dk_["launches"], 2),
+                        "traffic_source": None,
                         "algorithmic_bytes_per_launch": round(dk_["bytes"] / dk_["launches"], 1)}
+            if pmc and pmc.get("workload") == args.workload and not args.n and dom_name in pmc["kernels"]:
+                roofline["traffic"] = pmc["kernels"][dom_name]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/r01_pmc_traffic_enwik8like_1e8.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         fwd_ms = per["ms_sa"] + per["ms_bwt"]
         result = {
             "metric": "bwt_encode_MBps", "value": round(world * n * k / elapsed_max / 1e6, 3), "unit": "MB/s",
