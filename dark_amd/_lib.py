@@ -30,6 +30,7 @@ SIGNATURES = {
     "dk_ctx_create": (_i, [_i, _sz, C.POINTER(_vp)]),
     "dk_ctx_destroy": (None, [_vp]),
     "dk_capacity": (_sz, [_vp]),
+    "dk_last_consumed": (_sz, [_vp]),
     "dk_last_error": (C.c_char_p, [_vp]),
     "dk_suffix_array": (_i, [_vp, _vp, _sz, _vp]),
     "dk_bwt_forward": (_i, [_vp, _vp, _sz, _vp, _u32p]),

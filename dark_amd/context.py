@@ -70,6 +70,9 @@ class Context:
     def capacity(self):
         return int(self._lib.dk_capacity(self._h))
 
+    def last_consumed(self):
+        return int(self._lib.dk_last_consumed(self._h))
+
     # ---- host-pointer stage calls ----
     def suffix_array(self, data):
         t = as_u8(data)

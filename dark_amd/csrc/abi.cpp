@@ -116,7 +116,7 @@ int block_decode_common(dk_ctx *ctx, int model_id, const uint8_t *in, size_t in_
     uint32_t origin = 0;
     int single = 0;
     Timer t;
-    int rc = decode_block_stream(model_id, in, in_len, n, h_bwt, &origin, &single);
+    int rc = decode_block_stream(model_id, in, in_len, n, h_bwt, &origin, &single, &ctx->last_consumed);
     ctx->stats.ms_entropy = t.ms();
     if (rc) return ctx->fail(rc, "stream does not decode (corrupt, truncated, wrong model/size, or a block containing byte 0xFF, "
                                  "which the reference format cannot represent: src/block/dc.rs:57-73)");
@@ -183,6 +183,7 @@ void dk_ctx_destroy(dk_ctx *c) {
 }
 
 size_t dk_capacity(const dk_ctx *ctx) { return ctx ? ctx->max_n : 0; }
+size_t dk_last_consumed(const dk_ctx *ctx) { return ctx ? ctx->last_consumed : 0; }
 const char *dk_last_error(const dk_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 // ---- device-resident entry points ------------------------------------------------------------------------------------

@@ -63,6 +63,7 @@ struct dk_ctx {
     char *h_stage = nullptr;
     size_t h_stage_size = 0;
     std::string err;
+    size_t last_consumed = 0;  // bytes of coded stream the last block decode read (records can be concatenated)
     dk_stats stats{};
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;

@@ -602,12 +602,14 @@ int encode_block_stream(int model_id, const DcStream &s, uint8_t *out, size_t ca
 }
 
 int decode_block_stream(int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *bwt_out,
-                        uint32_t *origin, int *single) {
+                        uint32_t *origin, int *single, size_t *consumed) {
     if (!in || !bwt_out || !origin || n == 0) return DK_E_ARG;
     return with_model(model_id, [&](auto &model) {
         model.reset();  // src/block/dc.rs:108
         Decoder d(in, in_len);
-        return read_stream(model, d, n, bwt_out, origin, single);
+        int rc = read_stream(model, d, n, bwt_out, origin, single);
+        if (consumed) *consumed = d.consumed();
+        return rc;
     });
 }
 

@@ -127,6 +127,7 @@ public:
         return err_ == 0;
     }
     bool finish() { feed(); return err_ == 0; }  // ari::Decoder::finish consumes the pending tail bytes
+    size_t consumed() const { return pos_; }      // bytes read so far: after finish() = exactly what the encoder wrote
     int error() const { return err_; }
     bool fail(int e) { if (!err_) err_ = e; return false; }
 
@@ -355,7 +356,7 @@ int encode_block_stream(int model_id, const DcStream &s, uint8_t *out, size_t ca
 // src/block/dc.rs:121-151: header, dc::decode pulling model.decode, origin.  *single = 1 when the block has a
 // one-symbol alphabet (the reference then mis-reads origin; see DESIGN.md "Reference quirks").
 int decode_block_stream(int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *bwt_out,
-                        uint32_t *origin, int *single);
+                        uint32_t *origin, int *single, size_t *consumed = nullptr);
 // compress::bwt::dc::decode fed from an array
 int dc_decode_array(const uint32_t init[256], const uint32_t *dist, size_t m, uint8_t *bwt_out, size_t n, size_t *consumed);
 // model-level helpers (src/model/mod.rs:59-76)

@@ -75,6 +75,10 @@ int dk_block_encode(dk_ctx *ctx, int model_id, const uint8_t *in, size_t n,
                     uint8_t *out, size_t out_cap, size_t *out_len);
 /* block::Decoder::decode for block::dc::Decoder<M> src/block/dc.rs:119-160 */
 int dk_block_decode(dk_ctx *ctx, int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *out);
+/* Bytes of `in` the last dk_block_decode / dk_dev_block_decode on this context consumed (= the length the encoder wrote:
+ * 4 priming bytes + one per renormalisation shift).  Lets a caller walk concatenated [u32 n][stream] records -- the
+ * multi-block extension of the single-block file of src/main.rs:70,102. */
+size_t dk_last_consumed(const dk_ctx *ctx);
 
 /* ---- device-resident entry points (inputs already in HBM; used by pipelines and by bench.py) ----------------- */
 int dk_dev_suffix_array(dk_ctx *ctx, const uint8_t *d_in, size_t n, uint32_t *d_sa_out);

@@ -174,3 +174,35 @@ def test_mirror_interfaces(vectors, license_bytes):
         stream = enc.encode(data)
         dec = block.dc.Decoder(len(data), enc.model)
         assert dec.decode(stream) == data
+
+
+def test_cli_container(tmp_path, orc, license_bytes, monkeypatch):
+    # src/main.rs:87-113 / :56-83 through the CLI: FILE -> FILE.dark = [u32 LE n][stream]; FILE.dark -> FILE.orig
+    import struct
+    from dark_amd import cli
+    monkeypatch.chdir(tmp_path)
+    src = tmp_path / "book"
+    data = license_bytes * 40
+    src.write_bytes(data)
+    out = cli.encode_file(str(src), "dark", 0, 0)
+    blob = open(out, "rb").read()
+    assert out == "book.dark" and blob[:4] == struct.pack("<I", len(data))
+    assert blob[4:] == orc.block_dc_encode("dark", data)  # single block: byte-identical to the oracle's stream
+    assert open(cli.decode_file("book.dark", "dark", 0), "rb").read() == data
+    # multi-block extension: records are concatenated; each record alone is what a single-block run would write
+    out = cli.encode_file(str(src), "ybs", 10000, 0)
+    blob = open(out, "rb").read()
+    assert blob[:4] == struct.pack("<I", 10000)
+    first = orc.block_dc_encode("ybs", data[:10000])
+    assert blob[4:4 + len(first)] == first
+    assert open(cli.decode_file("book.dark", "ybs", 0), "rb").read() == data
+    cli.main(["-m", "exp", str(src)])
+    cli.main(["-m", "exp", "book.dark"])
+    assert open("book.orig", "rb").read() == data
+    # dump models (src/model/raw.rs): out.raw = origin (4 bytes, big-endian order) + BWT; out-dc.raw = 10-byte records
+    cli.encode_file(str(src), "raw", 0, 0)
+    bwt, origin = orc.bwt_forward(data)
+    assert open("out.raw", "rb").read() == struct.pack(">I", origin) + bwt.tobytes()
+    assert open("book.dark", "rb").read() == struct.pack("<I", len(data)) + b"\0\0\0\0"
+    cli.encode_file(str(src), "rawdc", 0, 0)
+    assert open("out-dc.raw", "rb").read() == orc.block_dc_encode("rawdc", data)
