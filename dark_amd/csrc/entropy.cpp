@@ -67,17 +67,18 @@ bool DarkModel::encode(uint32_t dist, uint8_t symbol, E &e) {  // dark.rs:180-23
     }
     last_token_ = token_of(log);
     BinFreq *mc = mantissa_[log];
-    for (unsigned i = 1; i < log; ++i) {  // mantissa below the leading one, MSB first
+    // mantissa below the leading one, MSB first: three adaptive bits, the rest through the never-updated 4th model (dark.rs:216-227)
+    const unsigned modelled = log > kMaxBitContext ? kMaxBitContext : log - 1;
+    for (unsigned i = 1; i <= modelled; ++i) {
         const bool bit = (v >> (log - i - 1)) & 1u;
-        if (i > kMaxBitContext) {
-            if (!encode_bit_p(e, mc[kMaxBitContext].zero, bit)) return false;  // 4th model never adapts (dark.rs:221)
-        } else {
-            if (!encode_bit_p(e, mc[i - 1].zero, bit)) return false;
-            mc[i - 1].learn<8>(bit);
-        }
+        if (!encode_bit_p(e, mc[i - 1].zero, bit)) return false;
+        mc[i - 1].learn<8>(bit);
     }
+    const uint32_t flat = mc[kMaxBitContext].zero;
+    for (unsigned i = kMaxBitContext + 1; i < log; ++i)
+        if (!encode_bit_p(e, flat, (v >> (log - i - 1)) & 1u)) return false;
     adapt(c, dist, static_cast<int>(log) - static_cast<int>(avg_log));
-    return e.error() == 0;
+    return true;
 }
 
 bool DarkModel::decode(uint8_t symbol, Decoder &d, uint32_t &dist) {  // dark.rs:234-287

@@ -55,17 +55,15 @@ class Encoder {
 public:
     Encoder(uint8_t *out, size_t cap) : out_(out), cap_(cap) {}
     // interval [from,to) out of total
+    // The models guarantee from < to <= total < 2^14 (frequencies stay >= 1, binary probabilities stay in [1, 4095]) and the
+    // coder keeps hi - low > 2^14 between symbols, so r >= 1: the hot path carries no validity branches.
     inline bool put(uint32_t total, uint32_t from, uint32_t to) {
-        if (!(from < to && to <= total)) return fail(DK_E_INTERNAL);
         const uint32_t r = (rs_.hi - rs_.low) / total;
-        if (r == 0) return fail(DK_E_INTERNAL);
         return emit_narrow(r, from, to);
     }
     // same with total == 1 << shift (bin models with threshold 4096, apm::Bit): the division becomes a shift
     inline bool put_pow2(unsigned shift, uint32_t from, uint32_t to) {
-        if (!(from < to && to <= (1u << shift))) return fail(DK_E_INTERNAL);
         const uint32_t r = (rs_.hi - rs_.low) >> shift;
-        if (r == 0) return fail(DK_E_INTERNAL);
         return emit_narrow(r, from, to);
     }
     bool finish() {  // ari::Encoder::finish: code tail = low, big-endian
