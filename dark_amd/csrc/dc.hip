@@ -156,24 +156,23 @@ __global__ __launch_bounds__(256) void k_dc_carry_c(uint32_t *__restrict__ tile_
 // scalar side): {last position + 1, run index + 1} of symbol c at index c (one 8-byte broadcast read / store).
 __device__ __forceinline__ uint32_t tab_index(uint32_t c) { return ((c & 63u) << 2) | (c >> 6); }
 
-// Five v_writelane_b32 at once: lane `sel` of every o* becomes the matching (wave-uniform) value.  gfx9 lets a VALU instruction
-// read one SGPR only, so the lane select goes through M0 (which does not count); M0 is saved and restored around the group.
-__device__ __forceinline__ void write_lane5(int sel, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t v4, uint32_t &o0,
-                                            uint32_t &o1, uint32_t &o2, uint32_t &o3, uint32_t &o4) {
+// One v_writelane_b32: lane `sel` of `old` becomes the (wave-uniform) value.  gfx9 lets a VALU instruction read one SGPR only, so
+// the lane select goes through M0 (which does not count); M0 is saved and restored.
+__device__ __forceinline__ uint32_t write_lane(uint32_t value, int sel, uint32_t old) {
     uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %5, m0\n\t"
-        "s_mov_b32 m0, %6\n\t"
-        "v_writelane_b32 %0, %7, m0\n\t"
-        "v_writelane_b32 %1, %8, m0\n\t"
-        "v_writelane_b32 %2, %9, m0\n\t"
-        "v_writelane_b32 %3, %10, m0\n\t"
-        "v_writelane_b32 %4, %11, m0\n\t"
-        "s_mov_b32 m0, %5"
-        : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3), "+v"(o4), "=&s"(keep)
-        : "s"(sel), "s"(v0), "s"(v1), "s"(v2), "s"(v3), "s"(v4));
+    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                 : "+v"(old), "=&s"(keep)
+                 : "s"(value), "s"(sel));
+    return old;
 }
 
+// One wave per tile.  Per 64-position chunk (lane = position) the ranks are found mostly lane-parallel:
+//   case A  the run's symbol already occurred in this chunk, last at lane w: rank = number of lanes q in (w, lane) that are the
+//           first of their symbol inside that window (prevsame[q] <= w), counted by shifting prevsame one lane per step;
+//   case B  first occurrence of the symbol in this chunk: previous occurrence b from the tile table (state before the chunk),
+//           rank = #{table symbols with last position > b} + #{symbols first seen in this chunk before the lane whose table
+//           position is <= b}; a short scalar loop over these lanes (at most one per distinct symbol of the chunk).
+// Then every run-start lane stores its own outputs, and the last lane of every symbol updates the tile table.
 __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict__ L, size_t n, size_t ntiles,
                                                        const uint32_t *__restrict__ carry_last, const uint32_t *__restrict__ carry_lrun,
                                                        const uint32_t *__restrict__ tile_run_base, uint32_t *__restrict__ dist,
@@ -197,64 +196,106 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
         pos[(lane << 2) | k] = cp;
         pr[k * 64 + lane] = make_uint2(cp, cr);
     }
-    // wave-uniform values are pinned to scalar registers: the per-run loop below is scalar control flow
-    uint32_t r = __builtin_amdgcn_readfirstlane(tile_run_base[tile]);  // index of the next run to start
-    const uint32_t base32 = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
+    uint32_t r = __builtin_amdgcn_readfirstlane(tile_run_base[tile]);  // index of the next run to start (wave-uniform)
+    const uint32_t base32 = static_cast<uint32_t>(base);
+    const uint64_t lt = lanemask_lt(lane), le = lt | (1ull << lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int chunk = 0; chunk < DC_TILE / 64; ++chunk) {
         const int j = chunk * 64 + lane;
         const size_t p = base + j;
+        const bool valid = p < n;
         const uint32_t c = s[DC_PAD + j];
         const uint32_t pc = s[DC_PAD + j - 1];
-        const bool start = p < n && (p == 0 || c != pc);
-        uint64_t m = __ballot(start);
-        if (m == 0) continue;
-        // Results of this chunk's runs are gathered lane by lane (v_writelane) and leave as ONE vector store per array:
-        // lane k ends up holding the k-th run of the chunk.
-        const uint32_t r0 = r;
-        uint32_t o_sym = 0, o_rank = 0, o_didx = 0xFFFFFFFFu, o_dval = 0, o_end = 0;
-        int k = 0;
-        do {
-            const int bit = __builtin_ctzll(m);
-            m &= m - 1;
-            const uint32_t i = base32 + static_cast<uint32_t>(chunk * 64 + bit);
-            const uint32_t cs = __builtin_amdgcn_readlane(c, bit);
-            const uint32_t ps = __builtin_amdgcn_readlane(pc, bit);
-            if (i > 0 && lane == 0) {  // the run of `ps` ended at i-1; it is run r-1
-                pos[tab_index(ps)] = i;
-                pr[ps] = make_uint2(i, r);
+        const bool start = valid && (p == 0 || c != pc);
+        const uint64_t S = __ballot(start);
+        if (S == 0) {
+            // no run starts here: nothing to emit; all valid lanes continue the open run (run r-1), whose table entry must still
+            // follow its last position in case the run ends exactly at this chunk's end
+            if (valid && (lane == 63 || p + 1 == n)) {
+                const uint32_t p1 = base32 + static_cast<uint32_t>(j) + 1u;
+                pos[tab_index(c)] = p1;
+                pr[c] = make_uint2(p1, r);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const uint2 prev = pr[cs];  // broadcast read; cs != ps, so the stores above do not touch it
-            const uint4 mine = *reinterpret_cast<const uint4 *>(pos + (lane << 2));
-            const uint32_t b1 = __builtin_amdgcn_readfirstlane(prev.x);
-            const uint32_t rb1 = __builtin_amdgcn_readfirstlane(prev.y);
-            // rank = number of symbols seen since the previous occurrence of cs (0 for a first occurrence: every entry > 0 = b1
-            // would count, so mask it out)
-            uint32_t cnt = static_cast<uint32_t>(__popcll(__ballot(mine.x > b1)) + __popcll(__ballot(mine.y > b1)) +
-                                                 __popcll(__ballot(mine.z > b1)) + __popcll(__ballot(mine.w > b1)));
-            cnt = b1 ? cnt : 0u;
-            if (b1 == 0 && lane == 0) init[cs] = i;  // first occurrence (at most 256 times per block)
-            // dval = i - b - rank - 1 with b = b1 - 1; o_end = end of the previous run (run r-1)
-            write_lane5(k, cs, cnt, b1 ? rb1 - 1 : 0xFFFFFFFFu, i - b1 - cnt, i - 1, o_sym, o_rank, o_didx, o_dval, o_end);
-            ++r;
-            ++k;
-        } while (m);
-        if (lane < k) {
-            sym[r0 + lane] = static_cast<uint8_t>(o_sym);
-            if (rank) rank[r0 + lane] = static_cast<uint8_t>(o_rank);
-            if (o_didx != 0xFFFFFFFFu) dist[o_didx] = o_dval;
-            if (run_end && r0 + lane > 0) run_end[r0 + lane - 1] = o_end;
+            continue;
         }
-    }
-    if (tile == ntiles - 1) {  // close the last run of the block and publish the final table for the sweep
-        const uint32_t ps = L[n - 1];
-        pos[tab_index(ps)] = static_cast<uint32_t>(n);
-        pr[ps] = make_uint2(static_cast<uint32_t>(n), r);
-        if (run_end && lane == 0) run_end[r - 1] = static_cast<uint32_t>(n - 1);
+        uint64_t same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (c >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            same &= bit ? bal : ~bal;
+        }
+        const uint64_t before = same & lt;
+        const int prevsame = before ? 63 - __builtin_clzll(before) : -1;  // previous lane with my symbol in this chunk
+        const uint2 tab = pr[c];                                           // table state BEFORE this chunk: {pos+1, run+1}
+        const uint4 mine = *reinterpret_cast<const uint4 *>(pos + (lane << 2));
+        const bool isA = start && prevsame >= 0;
+        const bool isB = start && prevsame < 0;
+        // ---- case A: distinct symbols in lanes (w, lane)
+        uint32_t cnt = 0;
+        {
+            const int w = prevsame;
+            int sh = prevsame;
+            for (int t = 1; t < 64; ++t) {
+                sh = __shfl_up(sh, 1, 64);  // lane l now holds prevsame[l - t]
+                const bool need = isA && t < lane - w;
+                if (__ballot(need) == 0) break;
+                cnt += (need && sh <= w) ? 1u : 0u;
+            }
+        }
+        // ---- case B: first occurrence of the symbol in this chunk; the previous one (if any) is in the table
+        {
+            const bool first_here = valid && prevsame < 0;
+            uint64_t mB = __ballot(isB);
+            while (mB) {
+                const int bit = __builtin_ctzll(mB);
+                mB &= mB - 1;
+                const uint32_t b1 = __builtin_amdgcn_readlane(tab.x, bit);
+                uint32_t rk = 0;
+                if (b1) {
+                    rk = static_cast<uint32_t>(__popcll(__ballot(mine.x > b1)) + __popcll(__ballot(mine.y > b1)) +
+                                               __popcll(__ballot(mine.z > b1)) + __popcll(__ballot(mine.w > b1)));
+                    const uint64_t extra = __ballot(first_here && tab.x <= b1) & ((1ull << bit) - 1ull);
+                    rk += static_cast<uint32_t>(__popcll(extra));
+                }
+                cnt = write_lane(rk, bit, cnt);
+            }
+        }
+        // ---- outputs of the run-start lanes
+        const uint32_t r0 = r;
+        if (start) {
+            const uint32_t i = base32 + static_cast<uint32_t>(j);
+            const uint32_t ridx = r0 + static_cast<uint32_t>(__popcll(S & lt));
+            sym[ridx] = static_cast<uint8_t>(c);
+            if (rank) rank[ridx] = static_cast<uint8_t>(cnt);
+            if (isA) {
+                const uint32_t b1 = base32 + static_cast<uint32_t>(chunk * 64 + prevsame) + 1u;
+                const uint32_t prun = r0 + static_cast<uint32_t>(__popcll(S & ((2ull << prevsame) - 1ull))) - 1u;  // run of lane w
+                dist[prun] = i - b1 - cnt;  // = i - b - rank - 1 with b = b1 - 1
+            } else if (tab.x) {
+                dist[tab.y - 1] = i - tab.x - cnt;
+            } else {
+                init[c] = i;  // first occurrence in the block
+            }
+            if (run_end && ridx > 0) run_end[ridx - 1] = i - 1;
+        }
+        // ---- table update: the last lane of every symbol of this chunk
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (same & ~le) == 0) {
+            const uint32_t p1 = base32 + static_cast<uint32_t>(j) + 1u;
+            const uint32_t run1 = r0 + static_cast<uint32_t>(__popcll(S & le));  // (index of the run holding this lane) + 1
+            pos[tab_index(c)] = p1;
+            pr[c] = make_uint2(p1, run1);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        r += static_cast<uint32_t>(__popcll(S));
+    }
+    if (tile == ntiles - 1) {  // publish the final table for the sweep (the last run ends at n-1: already in the table)
+        if (run_end && lane == 0) run_end[r - 1] = static_cast<uint32_t>(n - 1);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             final_last[k * 64 + lane] = pr[k * 64 + lane].x;
