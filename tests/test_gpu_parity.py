@@ -206,3 +206,31 @@ def test_cli_container(tmp_path, orc, license_bytes, monkeypatch):
     assert open("book.dark", "rb").read() == struct.pack("<I", len(data)) + b"\0\0\0\0"
     cli.encode_file(str(src), "rawdc", 0, 0)
     assert open("out-dc.raw", "rb").read() == orc.block_dc_encode("rawdc", data)
+
+
+def test_group_size_classes(ctx, orc):
+    # groups around the small/big threshold (64 members) at every alignment relative to the 2048-slot tiles of the local
+    # round kernel, plus deep repeats that stay unresolved for many doubling rounds
+    rng = np.random.default_rng(59)
+    parts = []
+    for g in list(range(60, 70)) + [2, 3, 127, 128, 129, 300, 2047, 2048, 2049] + [int(x) for x in rng.integers(2, 200, size=60)]:
+        motif = rng.integers(0, 250, size=int(rng.integers(12, 40)), dtype=np.uint8)
+        for _ in range(g):
+            parts.append(motif)
+            parts.append(rng.integers(0, 250, size=int(rng.integers(1, 4)), dtype=np.uint8))  # separator: copies diverge after the motif
+    deep = rng.integers(0, 4, size=20000, dtype=np.uint8)
+    parts += [deep, rng.integers(0, 250, size=100, dtype=np.uint8), deep, rng.integers(0, 250, size=7, dtype=np.uint8), deep]
+    order = rng.permutation(len(parts) - 5)
+    t = np.concatenate([parts[i] for i in order] + parts[-5:])
+    check_all_stages(ctx, orc, np.ascontiguousarray(t), models=("dark",))
+
+
+def test_bucketed_scatter_threshold(ctx, orc):
+    # the first rerank switches to the bucketed rank scatter at n = 2^22
+    rng = np.random.default_rng(61)
+    base = text_like(rng, (1 << 22) + 8, vocab=30000)
+    for n in ((1 << 22) - 1, 1 << 22, (1 << 22) + 1):
+        t = np.ascontiguousarray(base[:n])
+        sa = ctx.suffix_array(t)
+        want = orc.sa_sais(t)
+        assert first_diff(sa, want) is None, (n, first_diff(sa, want))
