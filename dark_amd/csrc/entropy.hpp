@@ -29,8 +29,13 @@ struct RangeState {
     // i.e. "shift out every equal leading byte, then stop if the range is wide enough, else cut and go round again".
     // All equal leading bytes leave in one step here (count-leading-zeros of lo^hi), through an unconditional 4-byte store:
     // `out` must have 8 writable bytes.  Returns the number of bytes shifted out (the reference allows at most 4), or -1.
-    inline int narrow(uint32_t r, uint32_t from, uint32_t to, uint8_t *out) {
-        uint32_t lo = low + r * from, h = low + r * to;
+    inline int narrow(uint32_t r, uint32_t from, uint32_t to, uint8_t *out) { return renorm(low + r * from, low + r * to, out); }
+    // binary decision under total 4096: [0, zero) codes 0, [zero, 4096) codes 1 -- one multiply, the bit only selects
+    inline int narrow_bit12(uint32_t r, uint32_t zero, bool one, uint8_t *out) {
+        const uint32_t t = r * zero;
+        return renorm(low + (one ? t : 0u), low + (one ? (r << 12) : t), out);
+    }
+    inline int renorm(uint32_t lo, uint32_t h, uint8_t *out) {
         int shifted = 0;
         for (;;) {
             const uint32_t x = lo ^ h;
@@ -66,6 +71,8 @@ public:
         const uint32_t r = (rs_.hi - rs_.low) >> shift;
         return emit_narrow(r, from, to);
     }
+    // (measured: two independent multiplies r*from, r*to beat one multiply followed by selects on the coder's critical path)
+    inline bool put_bit12(uint32_t zero, bool one) { return put_pow2(12, one ? zero : 0u, one ? 4096u : zero); }
     bool finish() {  // ari::Encoder::finish: code tail = low, big-endian
         if (len_ + 4 > cap_) return fail(DK_E_CAPACITY);
         for (int i = 0; i < 4; ++i) out_[len_++] = static_cast<uint8_t>(rs_.low >> (24 - 8 * i));
@@ -117,6 +124,21 @@ public:
     }
     // true when the decoded offset lies below `border` (i.e. offset < border)
     inline bool below(uint32_t border) const { return static_cast<uint64_t>(x_) < static_cast<uint64_t>(r_) * border; }
+    // binary decision under total 4096 in one step: offset >= zero  <=>  x >= r * zero
+    inline bool bit12(uint32_t zero, bool &one) {
+        feed();
+        const uint32_t r = (rs_.hi - rs_.low) >> 12;
+        const uint32_t x = code_ - rs_.low;
+        if (__builtin_expect(r == 0 || (x >> 12) >= r, 0)) return fail(DK_E_STREAM);
+        one = x >= r * zero;
+        uint8_t scratch[8];
+        const int k = rs_.narrow_bit12(r, zero, one, scratch);
+        if (__builtin_expect(k < 0, 0)) return fail(DK_E_STREAM);
+        pending_ = k;
+        return true;
+    }
+    uint32_t x() const { return x_; }
+    uint32_t r() const { return r_; }
     inline bool take(uint32_t from, uint32_t to) {
         uint8_t scratch[8];
         const int k = rs_.narrow(r_, from, to, scratch);
@@ -177,6 +199,7 @@ public:
         push(CodeEvent{static_cast<uint16_t>(from), static_cast<uint16_t>(to), 0, 0});
         return true;
     }
+    inline bool put_bit12(uint32_t zero, bool one) { return put_pow2(12, one ? zero : 0u, one ? 4096u : zero); }
     bool finish();  // flush the last batch and mark the end of the stream
     int error() const { return err_; }
     bool fail(int e) { if (!err_) err_ = e; return false; }
@@ -239,15 +262,17 @@ template <int N>
 inline bool decode_mix12(Decoder &d, const FreqTable<N> &a, const FreqTable<N> &b, size_t &v) {
     d.begin(a.total + 2u * b.total);
     if (d.error()) return false;
-    uint32_t lo = 0, hi = a.f[0] + 2u * b.f[0];
+    // symbol = number of cumulative borders at or below the offset; all N compares are independent (no search loop to mispredict)
+    uint32_t cum[N + 1];
+    cum[0] = 0;
+#pragma GCC unroll 8
+    for (int i = 0; i < N; ++i) cum[i + 1] = cum[i] + a.f[i] + 2u * b.f[i];
+    const uint64_t x = d.x(), r = d.r();
     size_t k = 0;
-    while (!d.below(hi)) {
-        if (++k >= static_cast<size_t>(N)) return d.fail(DK_E_STREAM);
-        lo = hi;
-        hi += a.f[k] + 2u * b.f[k];
-    }
+#pragma GCC unroll 8
+    for (int i = 1; i < N; ++i) k += x >= r * cum[i] ? 1u : 0u;  // x < r * cum[N] was checked by begin()
     v = k;
-    return d.take(lo, hi);
+    return d.take(cum[k], cum[k + 1]);
 }
 
 struct BinFreq {  // total is always kModelThreshold = 1 << 12 in the reference's models
@@ -262,15 +287,10 @@ struct BinFreq {  // total is always kModelThreshold = 1 << 12 in the reference'
 static_assert((1u << BinFreq::kShift) == kModelThreshold, "bin total must be a power of two");
 template <class E>
 inline bool encode_bit_p(E &e, uint32_t zero, bool one) {
-    const uint32_t from = one ? zero : 0u, to = one ? (1u << 12) : zero;
-    return e.put_pow2(12, from, to);
+    return e.put_bit12(zero, one);
 }
 inline bool decode_bit_p(Decoder &d, uint32_t zero, bool &one) {
-    d.begin_pow2(12);
-    if (d.error()) return false;
-    one = !d.below(zero);
-    const uint32_t from = one ? zero : 0u, to = one ? (1u << 12) : zero;
-    return d.take(from, to);
+    return d.bit12(zero, one);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
