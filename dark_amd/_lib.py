@@ -45,6 +45,7 @@ SIGNATURES = {
     "dk_dev_dc_encode": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _szp]),
     "dk_dev_block_encode": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _szp]),
     "dk_dev_block_decode": (_i, [_vp, _i, _vp, _sz, _sz, _vp]),
+    "dk_dev_batch_encode": (_i, [_vp, _i, _sz, _vp, _vp, _vp, _vp, _vp, _i]),
     "dk_model_encode": (_i, [_i, _vp, _vp, _sz, _vp, _sz, _szp]),
     "dk_model_decode": (_i, [_i, _vp, _sz, _vp, _sz, _vp]),
     "dk_bitcoder_encode": (_i, [_vp, _vp, _sz, _vp, _sz, _szp]),
@@ -68,6 +69,12 @@ def load():
         if not os.path.exists(SO_PATH):
             raise ImportError("dark_amd: %s is missing -- run `python dark_amd/build.py` (hipcc, gfx950). "
                               "There is no CPU fallback." % SO_PATH)
+        # PyTorch-ROCm ships its own libamdhip64 under the same soname as /opt/rocm's.  Whichever is loaded first serves the
+        # whole process; if ours came first, torch would later fail to find the GPU.  So when torch is installed, load it first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the ABI lacks a declared symbol

@@ -157,6 +157,19 @@ class Context:
         self._ck(self._lib.dk_dev_block_encode(self._h, mid, _ptr(d_in), n, _ptr(out), len(out), C.byref(ln)))
         return out[:ln.value]
 
+    def dev_batch_encode(self, model, d_blocks, sizes, host_threads=8, outs=None):
+        """d_blocks: device tensors / addresses; returns a list of coded streams (views of `outs` when given)"""
+        count = len(d_blocks)
+        if outs is None:
+            outs = [np.empty(2 * int(n) + 4096, dtype=np.uint8) for n in sizes]
+        ptrs = (C.c_void_p * count)(*[_ptr(b) for b in d_blocks])
+        ns = (C.c_size_t * count)(*[int(n) for n in sizes])
+        optrs = (C.c_void_p * count)(*[_ptr(o) for o in outs])
+        caps = (C.c_size_t * count)(*[len(o) for o in outs])
+        lens = (C.c_size_t * count)()
+        self._ck(self._lib.dk_dev_batch_encode(self._h, model_id(model), count, ptrs, ns, optrs, caps, lens, int(host_threads)))
+        return [o[:lens[i]] for i, o in enumerate(outs)]
+
     def dev_block_decode(self, model, stream, n, d_out):
         s = as_u8(stream)
         self._ck(self._lib.dk_dev_block_decode(self._h, model_id(model), _ptr(s), len(s), n, _ptr(d_out)))

@@ -1,7 +1,12 @@
 // extern "C" boundary (include/dark_amd.h).  Thin: argument checks, workspace carving, stage sequencing, timing.
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <new>
+#include <thread>
+#include <vector>
 
 #include "context.hpp"
 #include "entropy.hpp"
@@ -46,7 +51,8 @@ struct ForwardResult {
     const uint32_t *run_end = nullptr;
 };
 
-int forward_to_stream(dk_ctx *ctx, const uint8_t *d_text, size_t n, bool want_ctx_fields, ForwardResult *fr) {
+// slot < 0: the context's single staging buffer; otherwise the batch staging slot of that index
+int forward_to_stream(dk_ctx *ctx, const uint8_t *d_text, size_t n, bool want_ctx_fields, ForwardResult *fr, int slot = -1) {
     hipStream_t st = ctx->stream;
     uint8_t *d_bwt = ctx->ws_alloc<uint8_t>(n);
     uint32_t *d_dist = ctx->ws_alloc<uint32_t>(n);
@@ -73,20 +79,27 @@ int forward_to_stream(dk_ctx *ctx, const uint8_t *d_text, size_t n, bool want_ct
     Timer t4;
     const size_t m = fr->m;
     const size_t off_sym = 4 * m, off_rank = off_sym + ((m + 15) & ~size_t(15)), off_end = off_rank + ((m + 15) & ~size_t(15));
-    DK_TRY(ctx->ensure_stage(off_end + 4 * m + 64));
-    DK_HIP(ctx, hipMemcpyAsync(ctx->h_stage, d_dist, 4 * m, hipMemcpyDeviceToHost, st));
-    DK_HIP(ctx, hipMemcpyAsync(ctx->h_stage + off_sym, d_sym, m, hipMemcpyDeviceToHost, st));
+    char *stage;
+    if (slot < 0) {
+        DK_TRY(ctx->ensure_stage(off_end + 4 * m + 64));
+        stage = ctx->h_stage;
+    } else {
+        DK_TRY(ctx->ensure_slot(static_cast<size_t>(slot), off_end + 4 * m + 64));
+        stage = ctx->slots[static_cast<size_t>(slot)].h;
+    }
+    DK_HIP(ctx, hipMemcpyAsync(stage, d_dist, 4 * m, hipMemcpyDeviceToHost, st));
+    DK_HIP(ctx, hipMemcpyAsync(stage + off_sym, d_sym, m, hipMemcpyDeviceToHost, st));
     if (want_ctx_fields) {
-        DK_HIP(ctx, hipMemcpyAsync(ctx->h_stage + off_rank, d_rank, m, hipMemcpyDeviceToHost, st));
-        DK_HIP(ctx, hipMemcpyAsync(ctx->h_stage + off_end, d_run_end, 4 * m, hipMemcpyDeviceToHost, st));
+        DK_HIP(ctx, hipMemcpyAsync(stage + off_rank, d_rank, m, hipMemcpyDeviceToHost, st));
+        DK_HIP(ctx, hipMemcpyAsync(stage + off_end, d_run_end, 4 * m, hipMemcpyDeviceToHost, st));
     }
     DK_HIP(ctx, hipStreamSynchronize(st));
     ctx->stats.ms_d2h = t4.ms();
-    fr->dist = reinterpret_cast<const uint32_t *>(ctx->h_stage);
-    fr->sym = reinterpret_cast<const uint8_t *>(ctx->h_stage + off_sym);
+    fr->dist = reinterpret_cast<const uint32_t *>(stage);
+    fr->sym = reinterpret_cast<const uint8_t *>(stage + off_sym);
     if (want_ctx_fields) {
-        fr->rank = reinterpret_cast<const uint8_t *>(ctx->h_stage + off_rank);
-        fr->run_end = reinterpret_cast<const uint32_t *>(ctx->h_stage + off_end);
+        fr->rank = reinterpret_cast<const uint8_t *>(stage + off_rank);
+        fr->run_end = reinterpret_cast<const uint32_t *>(stage + off_end);
     }
     return DK_OK;
 }
@@ -178,6 +191,7 @@ void dk_ctx_destroy(dk_ctx *c) {
     if (c->d_mail) (void)hipFree(c->d_mail);
     if (c->h_mail) (void)hipHostFree(c->h_mail);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (auto &sl : c->slots) if (sl.h) (void)hipHostFree(sl.h);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -262,6 +276,88 @@ int dk_dev_block_decode(dk_ctx *ctx, int model_id, const uint8_t *in, size_t in_
     int rc = block_decode_common(ctx, model_id, in, in_len, n, d_out);
     ctx->stats.ms_total = t.ms();
     return rc;
+}
+
+// Batch of independent blocks on one GPU: the device stages run block after block on the context's stream while a pool of host
+// threads codes the distance streams of the blocks already done (the "one block per core, pipelined against the GPU work of
+// the next block" deployment of SURVEY.md section 7.8).  Every out[i] is byte-identical to a dk_dev_block_encode of block i.
+int dk_dev_batch_encode(dk_ctx *ctx, int model_id, size_t count, const uint8_t *const *d_in, const size_t *n, uint8_t *const *out,
+                        const size_t *out_cap, size_t *out_len, int host_threads) {
+    DK_TRY(begin_call(ctx));
+    ScopedCall sc(ctx);
+    if (!d_in || !n || !out || !out_cap || !out_len || count == 0) return ctx->fail(DK_E_ARG, "null pointer or empty batch");
+    if (model_max_block(model_id) == 0) return ctx->fail(DK_E_MODEL, "unknown model id %d", model_id);
+    for (size_t i = 0; i < count; ++i) {
+        if (!d_in[i] || !out[i]) return ctx->fail(DK_E_ARG, "null pointer in block %zu", i);
+        DK_TRY(check_n(ctx, n[i]));
+        if (n[i] > model_max_block(model_id)) return ctx->fail(DK_E_MODEL, "model %d cannot code a block of %zu bytes", model_id, n[i]);
+    }
+    Timer t;
+    const size_t workers = static_cast<size_t>(std::max(1, std::min<int>(host_threads, static_cast<int>(count))));
+    const size_t nslots = workers + 1;
+    struct Job { size_t block; int slot; ForwardResult fr; };
+    std::mutex mu;
+    std::condition_variable cv_job, cv_slot;
+    std::deque<Job> queue;
+    std::vector<int> free_slots;
+    for (size_t k = 0; k < nslots; ++k) free_slots.push_back(static_cast<int>(k));
+    bool done = false;
+    std::vector<int> rcs(count, DK_OK);
+    auto worker = [&] {
+        for (;;) {
+            Job job;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [&] { return done || !queue.empty(); });
+                if (queue.empty()) return;
+                job = queue.front();
+                queue.pop_front();
+            }
+            DcStream s;
+            s.n = n[job.block]; s.init = job.fr.init; s.dist = job.fr.dist; s.sym = job.fr.sym; s.rank = job.fr.rank;
+            s.run_end = job.fr.run_end; s.m = job.fr.m; s.origin = job.fr.origin;
+            rcs[job.block] = encode_block_stream(model_id, s, out[job.block], out_cap[job.block], &out_len[job.block]);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                free_slots.push_back(job.slot);
+            }
+            cv_slot.notify_one();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (size_t w = 0; w < workers; ++w) pool.emplace_back(worker);
+    int rc = DK_OK;
+    for (size_t i = 0; i < count && rc == DK_OK; ++i) {
+        int slot;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_slot.wait(lk, [&] { return !free_slots.empty(); });
+            slot = free_slots.back();
+            free_slots.pop_back();
+        }
+        Job job;
+        job.block = i;
+        job.slot = slot;
+        ctx->ws_reset();
+        rc = forward_to_stream(ctx, d_in[i], n[i], model_id == DK_MODEL_RAWDC, &job.fr, slot);
+        if (rc != DK_OK) break;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            queue.push_back(job);
+        }
+        cv_job.notify_one();
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        done = true;
+    }
+    cv_job.notify_all();
+    for (auto &th : pool) th.join();
+    ctx->stats.ms_total = t.ms();
+    if (rc != DK_OK) return rc;
+    for (size_t i = 0; i < count; ++i)
+        if (rcs[i] != DK_OK) return ctx->fail(rcs[i], "entropy stage of block %zu failed (%d)", i, rcs[i]);
+    return DK_OK;
 }
 
 // ---- host-pointer entry points: stage in, run the device path, stage out ---------------------------------------------

@@ -81,3 +81,17 @@ int dk_ctx::ensure_stage(size_t bytes) {
     h_stage_size = bytes;
     return DK_OK;
 }
+
+int dk_ctx::ensure_slot(size_t index, size_t bytes) {
+    if (slots.size() <= index) slots.resize(index + 1);
+    StageSlot &sl = slots[index];
+    if (bytes <= sl.cap) return DK_OK;
+    if (sl.h) (void)hipHostFree(sl.h);
+    sl.h = nullptr;
+    sl.cap = 0;
+    const size_t want = bytes + bytes / 8;  // a little slack so that blocks of similar size do not re-allocate
+    if (hipHostMalloc(reinterpret_cast<void **>(&sl.h), want, hipHostMallocDefault) != hipSuccess)
+        return fail(DK_E_NOMEM, "pinned staging slot of %zu bytes failed", want);
+    sl.cap = want;
+    return DK_OK;
+}

@@ -62,6 +62,10 @@ struct dk_ctx {
     // pinned staging for D2H of the DC stream
     char *h_stage = nullptr;
     size_t h_stage_size = 0;
+    // extra pinned staging slots for the batch entry point (one block being coded per host thread, one being filled)
+    struct StageSlot { char *h = nullptr; size_t cap = 0; };
+    std::vector<StageSlot> slots;
+    int ensure_slot(size_t index, size_t bytes);
     std::string err;
     size_t last_consumed = 0;  // bytes of coded stream the last block decode read (records can be concatenated)
     dk_stats stats{};

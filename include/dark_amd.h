@@ -90,6 +90,11 @@ int dk_dev_dc_encode(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t init[
 /* whole forward path from a device-resident block to the coded stream in host memory */
 int dk_dev_block_encode(dk_ctx *ctx, int model_id, const uint8_t *d_in, size_t n,
                         uint8_t *out, size_t out_cap, size_t *out_len);
+/* `count` independent blocks on one GPU, pipelined: the device stages of block i+1 run while up to `host_threads` host threads
+ * code the distance streams of earlier blocks (the reference treats every block as self-contained: fresh model and coder per
+ * Encoder::new, src/block/dc.rs:30-37,53).  out[i] / out_len[i] are exactly what dk_dev_block_encode gives for block i. */
+int dk_dev_batch_encode(dk_ctx *ctx, int model_id, size_t count, const uint8_t *const *d_in, const size_t *n,
+                        uint8_t *const *out, const size_t *out_cap, size_t *out_len, int host_threads);
 /* whole inverse path from a coded stream in host memory to a device-resident block */
 int dk_dev_block_decode(dk_ctx *ctx, int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *d_out);
 

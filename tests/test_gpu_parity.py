@@ -234,3 +234,16 @@ def test_bucketed_scatter_threshold(ctx, orc):
         sa = ctx.suffix_array(t)
         want = orc.sa_sais(t)
         assert first_diff(sa, want) is None, (n, first_diff(sa, want))
+
+
+def test_batch_encode_matches_single(ctx, orc):
+    # dk_dev_batch_encode: device stages pipelined against host coding threads; every stream equals the single-block result
+    import torch
+    rng = np.random.default_rng(67)
+    blocks = [text_like(rng, int(n)) for n in (50000, 120000, 777, 300001, 64000, 9)]
+    d_blocks = [torch.from_numpy(b.copy()).cuda() for b in blocks]
+    streams = ctx.dev_batch_encode("dark", d_blocks, [len(b) for b in blocks], host_threads=3)
+    for b, s in zip(blocks, streams):
+        assert s.tobytes() == orc.block_dc_encode("dark", b)
+    streams = ctx.dev_batch_encode("ybs", d_blocks[:2], [len(b) for b in blocks[:2]], host_threads=8)
+    assert streams[1].tobytes() == ctx.block_encode("ybs", blocks[1])
