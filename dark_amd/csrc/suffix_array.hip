@@ -215,7 +215,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
         const size_t hs = el >> 1;
         const uint32_t head_pos = !pos_in ? static_cast<uint32_t>(hs) : (hs >= b0 ? s_pos[hs - b0] : pos_in[hs]);
         if (headpos_out) headpos_out[a] = head_pos;  // first rerank of a large block: ranks are stored by the bucketed scatter
-        else if (!(el & 1u)) rank[suffix] = head_pos;  // members of a group that kept its head keep their rank: no scatter
+        else if (rank && !(el & 1u)) rank[suffix] = head_pos;  // members of a group that kept its head keep their rank: no scatter
         if (!(f & F_SURV)) {
             sa[my_pos[j]] = suffix;  // the group is a singleton: this suffix is in its final place
         } else {
@@ -234,8 +234,12 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
     }
 }
 
+// probe_active (first rerank only): read the number of surviving slots back after the reduce/scan phases; when it is zero the
+// initial sort already separated every suffix (random bytes, small alphabets with long keys) and nobody will ever read the
+// rank array, so the apply phase only writes SA.
 int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_t *pos_in, size_t count, int gshift, uint32_t *rank,
-           uint32_t *sa, uint32_t *out_idx, uint32_t *out_pos, uint32_t *out_gid, uint32_t *gstart, uint32_t *headpos_out = nullptr) {
+           uint32_t *sa, uint32_t *out_idx, uint32_t *out_pos, uint32_t *out_gid, uint32_t *gstart, uint32_t *headpos_out = nullptr,
+           bool probe_active = false, bool *ranks_written = nullptr) {
     const size_t ntiles = div_up(count, RR_TILE);
     const size_t mark = ctx->ws_mark();
     RerankAgg *agg = ctx->ws_alloc<RerankAgg>(ntiles);
@@ -248,6 +252,16 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
     {
         LaunchScope ls(ctx, K_RERANK_SCAN, 32.0 * ntiles);
         k_rerank_scan<<<dim3(1), dim3(1024), 0, st>>>(agg, ntiles, ctx->d_mail, gstart);
+    }
+    if (ranks_written) *ranks_written = true;
+    if (probe_active) {
+        DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        DK_HIP(ctx, hipStreamSynchronize(st));
+        if (ctx->h_mail[0] == 0) {  // nothing survives: ranks are dead values
+            rank = nullptr;
+            headpos_out = nullptr;
+            if (ranks_written) *ranks_written = false;
+        }
     }
     {
         LaunchScope ls(ctx, K_RERANK_APPLY, 8.0 * count + 4.0 * count + 4.0 * count + 12.0 * count);
@@ -486,10 +500,11 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     if (bucketed && n >= (1u << 22)) {
         // rank[suffix] = head position for all n suffixes: too random for plain stores (every 4-byte store is a 64-byte line
         // at the HBM) -> the rerank only lists the head positions, the bucketed scatter stores them XCD-locally
-        DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, rank, d_sa, vals_alt, pos, gid, gstart, vals_3));
-        DK_TRY(scatter_u32_bucketed(ctx, vals, vals_3, n, n, keys_alt, rank));
+        bool need_ranks = true;
+        DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, rank, d_sa, vals_alt, pos, gid, gstart, vals_3, true, &need_ranks));
+        if (need_ranks) DK_TRY(scatter_u32_bucketed(ctx, vals, vals_3, n, n, keys_alt, rank));
     } else {
-        DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, rank, d_sa, vals_alt, pos, gid, gstart));
+        DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, rank, d_sa, vals_alt, pos, gid, gstart, nullptr, true));
     }
     DK_TRY(classify_and_read(ctx, n / 2, gstart, bigstart, &active, &groups, &nbig));
     std::swap(vals, vals_alt);  // vals = suffix indices of the active list
