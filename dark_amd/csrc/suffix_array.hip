@@ -33,21 +33,66 @@ __global__ __launch_bounds__(256) void k_sym_hist(const uint8_t *__restrict__ t,
     if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
 
-__global__ __launch_bounds__(256) void k_pack_keys(const uint8_t *__restrict__ t, size_t n, const uint8_t *__restrict__ code,
-                                                    int bits, int spk, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx) {
+// key[i] = codes of T[i .. i+spk) packed big-endian (zero padded past the end), idx[i] = i.
+// A workgroup stages the codes of its 2048 positions (+ spk look-ahead) in LDS with one table lookup per text byte; each thread
+// then builds the keys of 8 consecutive positions with a sliding window: key(i+1) = (key(i) << bits | code(T[i+spk])) & mask.
+constexpr int PK_BLOCK = 256;
+constexpr int PK_G = 8;
+constexpr int PK_TILE = PK_BLOCK * PK_G;
+constexpr int PK_AHEAD = 64 + 8;  // spk <= 64
+
+__global__ __launch_bounds__(PK_BLOCK) void k_pack_keys(const uint8_t *__restrict__ t, size_t n, const uint8_t *__restrict__ code,
+                                                         int bits, int spk, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx) {
     __shared__ uint8_t s_code[256];
-    s_code[threadIdx.x] = code[threadIdx.x];
+    __shared__ __attribute__((aligned(16))) uint8_t s_c[PK_TILE + PK_AHEAD + 16];
+    const int tid = threadIdx.x;
+    s_code[tid] = code[tid];
     __syncthreads();
-    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t key = 0;
-    for (int j = 0; j < spk; ++j) {
-        const size_t p = i + j;
-        const uint64_t c = p < n ? s_code[t[p]] : 0;
-        key = (key << bits) | c;
+    const size_t b0 = static_cast<size_t>(blockIdx.x) * PK_TILE;
+    const bool aligned = (reinterpret_cast<uintptr_t>(t) & 15) == 0;
+    for (int o = tid * 16; o < PK_TILE + PK_AHEAD; o += PK_BLOCK * 16) {
+        const size_t p = b0 + o;
+        uint8_t raw[16];
+        if (aligned && p + 16 <= n) {
+            *reinterpret_cast<uint4 *>(raw) = *reinterpret_cast<const uint4 *>(t + p);
+#pragma unroll
+            for (int b = 0; b < 16; ++b) raw[b] = s_code[raw[b]];
+        } else {
+#pragma unroll
+            for (int b = 0; b < 16; ++b) raw[b] = (p + b < n) ? s_code[t[p + b]] : 0;  // zero padding past the end of the text
+        }
+        *reinterpret_cast<uint4 *>(s_c + o) = *reinterpret_cast<const uint4 *>(raw);
     }
-    keys[i] = key;
-    idx[i] = static_cast<uint32_t>(i);
+    __syncthreads();
+    const int base = tid * PK_G;
+    const size_t i0 = b0 + base;
+    if (i0 >= n) return;
+    const uint64_t mask = (spk * bits >= 64) ? ~0ull : ((1ull << (spk * bits)) - 1ull);
+    uint64_t key = 0;
+    for (int j = 0; j < spk; ++j) key = (key << bits) | s_c[base + j];
+    uint64_t out[PK_G];
+    out[0] = key;
+#pragma unroll
+    for (int g = 1; g < PK_G; ++g) {
+        key = ((key << bits) | s_c[base + spk + g - 1]) & mask;
+        out[g] = key;
+    }
+    if (i0 + PK_G <= n) {
+        uint4 *kp = reinterpret_cast<uint4 *>(keys + i0);
+#pragma unroll
+        for (int g = 0; g < PK_G; g += 2)
+            kp[g / 2] = make_uint4(static_cast<uint32_t>(out[g]), static_cast<uint32_t>(out[g] >> 32), static_cast<uint32_t>(out[g + 1]),
+                                   static_cast<uint32_t>(out[g + 1] >> 32));
+        uint4 *ip = reinterpret_cast<uint4 *>(idx + i0);
+        const uint32_t i32 = static_cast<uint32_t>(i0);
+        ip[0] = make_uint4(i32, i32 + 1, i32 + 2, i32 + 3);
+        ip[1] = make_uint4(i32 + 4, i32 + 5, i32 + 6, i32 + 7);
+    } else {
+        for (int g = 0; g < PK_G && i0 + g < n; ++g) {
+            keys[i0 + g] = out[g];
+            idx[i0 + g] = static_cast<uint32_t>(i0 + g);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_sa_descending(uint32_t *__restrict__ sa, size_t n) {
@@ -489,7 +534,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     // 2.-3. initial keys and sort
     {
         LaunchScope ls(ctx, K_PACK_KEYS, 1.0 * n + 12.0 * n);
-        k_pack_keys<<<dim3(div_up(n, 256)), dim3(256), 0, st>>>(d_text, n, d_code, bits, spk, keys, vals);
+        k_pack_keys<<<dim3(div_up(n, PK_TILE)), dim3(PK_BLOCK), 0, st>>>(d_text, n, d_code, bits, spk, keys, vals);
     }
     DK_HIP(ctx, hipGetLastError());
     DK_TRY(sort_pairs(ctx, keys, keys_alt, vals, vals_alt, n, 0, bits * spk));
