@@ -36,22 +36,42 @@ __device__ __forceinline__ uint64_t load_key(const uint64_t *__restrict__ keys, 
     return keys[i];
 }
 
+// 16 private copies of the histogram (copy = lane mod 16): text digits are skewed, and LDS atomics of one wave instruction that
+// hit the same address are serialised; spreading them over copies cuts that contention up to 16 x.
+constexpr int RS_HCOPIES = 16;
+
 template <bool PAIRS>
 __global__ __launch_bounds__(RS_BLOCK) void k_radix_hist(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ hi,
                                                           const uint32_t *__restrict__ lo, size_t n, int shift,
                                                           uint32_t *__restrict__ tile_hist) {
-    __shared__ uint32_t h[256];
+    __shared__ uint32_t h[RS_HCOPIES][256];
     const int tid = threadIdx.x;
-    h[tid] = 0;
-    __syncthreads();
-    const size_t base = static_cast<size_t>(blockIdx.x) * RS_TILE;
 #pragma unroll
-    for (int k = 0; k < RS_KPT; ++k) {
-        const size_t i = base + static_cast<size_t>(k) * RS_BLOCK + tid;
-        if (i < n) atomicAdd(&h[digit_of(load_key<PAIRS>(keys, hi, lo, i), shift)], 1u);
+    for (int c = 0; c < RS_HCOPIES; ++c) h[c][tid] = 0;
+    __syncthreads();
+    uint32_t *mine = h[tid & (RS_HCOPIES - 1)];
+    const size_t base = static_cast<size_t>(blockIdx.x) * RS_TILE;
+    if (!PAIRS && base + RS_TILE <= n) {  // full tile: two keys per 16-byte load (order inside the tile is irrelevant here)
+        const uint4 *p = reinterpret_cast<const uint4 *>(keys + base);
+#pragma unroll
+        for (int k = 0; k < RS_KPT / 2; ++k) {
+            const uint4 v = p[k * RS_BLOCK + tid];
+            const uint64_t k0 = (static_cast<uint64_t>(v.y) << 32) | v.x, k1 = (static_cast<uint64_t>(v.w) << 32) | v.z;
+            atomicAdd(&mine[digit_of(k0, shift)], 1u);
+            atomicAdd(&mine[digit_of(k1, shift)], 1u);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < RS_KPT; ++k) {
+            const size_t i = base + static_cast<size_t>(k) * RS_BLOCK + tid;
+            if (i < n) atomicAdd(&mine[digit_of(load_key<PAIRS>(keys, hi, lo, i), shift)], 1u);
+        }
     }
     __syncthreads();
-    tile_hist[static_cast<size_t>(blockIdx.x) * 256 + tid] = h[tid];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int c = 0; c < RS_HCOPIES; ++c) sum += h[c][tid];
+    tile_hist[static_cast<size_t>(blockIdx.x) * 256 + tid] = sum;
 }
 
 // phase A: per chunk of tiles, per digit: sum of the tile counts
