@@ -206,6 +206,16 @@ def main():
                 roofline["traffic"] = pmc["kernels"][dom_name]["hbm_bytes_per_launch"]
                 roofline["traffic_source"] = "profiles/r01_pmc_traffic_enwik8like_1e8.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         fwd_ms = per["ms_sa"] + per["ms_bwt"]
+        # BWT-forward roofline the way SURVEY 8(d) defines it: min(B_fwd formula, PMC-measured HBM bytes) / t_fwd against the 8 TB/s peak
+        fwd_roofline = None
+        if pmc and pmc.get("workload") == args.workload and not args.n:
+            P = 2 * -(-max(1, (n - 1).bit_length()) // 8)
+            R = stats["rounds"]
+            b_formula = n * (85 + R * (44 + 24 * P) + 6)
+            measured = sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for kk, v in pmc["kernels"].items() if not kk.startswith("k_dc_"))
+            ach = min(b_formula, measured) / (fwd_ms * 1e-3) / 1e9
+            fwd_roofline = {"B_fwd_formula_bytes": b_formula, "rounds": R, "passes_P": P, "measured_hbm_bytes": round(measured),
+                            "t_fwd_ms": round(fwd_ms, 3), "achieved_GBs": round(ach, 1), "frac_of_8TBs": round(ach / HBM_PEAK_GBS, 4)}
         result = {
             "metric": "bwt_encode_MBps", "value": round(world * n * k / elapsed_max / 1e6, 3), "unit": "MB/s",
             "n_gpus": world, "steps": k, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed_max / k, 3),
@@ -221,6 +231,7 @@ def main():
             "sa_rounds": stats["rounds"], "sort_passes": stats["sort_passes"], "dc_runs": stats["dc_runs"],
             "kernel_ms_per_step": {kk: round(v["ms"] / k, 3) for kk, v in sorted(kern.items(), key=lambda x: -x[1]["ms"])},
             "roofline": roofline,
+            "bwt_forward_roofline": fwd_roofline,
             "pipelined": pipelined,
             "datagen_s": round(t_gen, 2),
         }
