@@ -462,8 +462,19 @@ __global__ __launch_bounds__(256) void k_big_back(const uint64_t *__restrict__ b
 }
 
 // enqueue the classification of the groups rerank() just produced and read back (active, groups, big slots)
-int classify_and_read(dk_ctx *ctx, size_t max_groups, uint32_t *gstart, uint32_t *bigstart, size_t *active, size_t *groups, size_t *nbig) {
+// all_small: every group of the list that was just reranked was small (<= LS_MAX); its children are subsets, so nothing can be
+// big any more and the classification kernels are skipped for good.
+int classify_and_read(dk_ctx *ctx, size_t max_groups, uint32_t *gstart, uint32_t *bigstart, size_t *active, size_t *groups, size_t *nbig,
+                      bool all_small = false) {
     hipStream_t st = ctx->stream;
+    if (all_small) {
+        DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        DK_HIP(ctx, hipStreamSynchronize(st));
+        *active = ctx->h_mail[0];
+        *groups = ctx->h_mail[1];
+        *nbig = 0;
+        return DK_OK;
+    }
     const size_t mark = ctx->ws_mark();
     const size_t ntiles = div_up(max_groups + 1, BG_TILE);
     uint32_t *part = ctx->ws_alloc<uint32_t>(ntiles);
@@ -585,7 +596,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
         // keys / vals_alt now hold every group sorted by rank2 in its own slot range
         size_t next_active = 0, next_groups = 0, next_big = 0;
         DK_TRY(rerank(ctx, keys, vals_alt, pos, active, kbits, rank, d_sa, vals, pos_alt, gid_alt, gstart));
-        DK_TRY(classify_and_read(ctx, active / 2, gstart, bigstart, &next_active, &next_groups, &next_big));
+        DK_TRY(classify_and_read(ctx, active / 2, gstart, bigstart, &next_active, &next_groups, &next_big, nbig == 0));
         std::swap(pos, pos_alt);
         std::swap(gid, gid_alt);
         if (trace)
