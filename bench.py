@@ -178,6 +178,18 @@ def main():
             pipelined = {"blocks_per_gpu": B, "host_threads": args.pipeline_threads, "MBps": round(world * B * n / float(dtp.item()) / 1e6, 1),
                          "seconds": round(float(dtp.item()), 3), "streams_identical_to_single_block_path": bool(same)}
             del warm
+            if not args.no_decode and roundtrip_ok is True:
+                d_outs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(B)]
+                barrier()
+                tp = time.perf_counter()
+                ctx.dev_batch_decode(args.model, res, [n] * B, d_outs, args.pipeline_threads)
+                barrier()
+                dtd = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device=dev)
+                if world > 1:
+                    dist.all_reduce(dtd, op=dist.ReduceOp.MAX)
+                pipelined["decode_MBps"] = round(world * B * n / float(dtd.item()) / 1e6, 1)
+                pipelined["decode_roundtrip_ok"] = bool(all(torch.equal(o, d_in) for o in (d_outs[0], d_outs[-1])))
+                del d_outs
         except dark_amd.DarkError as e:
             pipelined = {"error": str(e)}
         del outs

@@ -170,6 +170,15 @@ class Context:
         self._ck(self._lib.dk_dev_batch_encode(self._h, model_id(model), count, ptrs, ns, optrs, caps, lens, int(host_threads)))
         return [o[:lens[i]] for i, o in enumerate(outs)]
 
+    def dev_batch_decode(self, model, streams, sizes, d_outs, host_threads=8):
+        count = len(streams)
+        keep = [as_u8(x) for x in streams]
+        ins = (C.c_void_p * count)(*[_ptr(x) for x in keep])
+        lens = (C.c_size_t * count)(*[len(x) for x in keep])
+        ns = (C.c_size_t * count)(*[int(n) for n in sizes])
+        outs = (C.c_void_p * count)(*[_ptr(o) for o in d_outs])
+        self._ck(self._lib.dk_dev_batch_decode(self._h, model_id(model), count, ins, lens, ns, outs, int(host_threads)))
+
     def dev_block_decode(self, model, stream, n, d_out):
         s = as_u8(stream)
         self._ck(self._lib.dk_dev_block_decode(self._h, model_id(model), _ptr(s), len(s), n, _ptr(d_out)))

@@ -360,6 +360,101 @@ int dk_dev_batch_encode(dk_ctx *ctx, int model_id, size_t count, const uint8_t *
     return DK_OK;
 }
 
+// Inverse of dk_dev_batch_encode: host threads decode the streams (range decoder + dc::decode, serial per block) into pinned
+// slots while the calling thread uploads finished BWTs and runs the inverse BWT on the GPU.
+int dk_dev_batch_decode(dk_ctx *ctx, int model_id, size_t count, const uint8_t *const *in, const size_t *in_len, const size_t *n,
+                        uint8_t *const *d_out, int host_threads) {
+    DK_TRY(begin_call(ctx));
+    ScopedCall sc(ctx);
+    if (!in || !in_len || !n || !d_out || count == 0) return ctx->fail(DK_E_ARG, "null pointer or empty batch");
+    if (model_id == DK_MODEL_RAWDC || model_max_block(model_id) == 0) return ctx->fail(DK_E_MODEL, "model %d cannot decode", model_id);
+    size_t max_n = 0;
+    for (size_t i = 0; i < count; ++i) {
+        if (!in[i] || !d_out[i]) return ctx->fail(DK_E_ARG, "null pointer in block %zu", i);
+        DK_TRY(check_n(ctx, n[i]));
+        max_n = std::max(max_n, n[i]);
+    }
+    Timer t;
+    const size_t workers = static_cast<size_t>(std::max(1, std::min<int>(host_threads, static_cast<int>(count))));
+    const size_t nslots = workers + 1;
+    for (size_t k = 0; k < nslots; ++k) DK_TRY(ctx->ensure_slot(k, max_n + 64));
+    struct Done { size_t block; int slot; uint32_t origin; int single; int rc; };
+    std::mutex mu;
+    std::condition_variable cv_slot, cv_done;
+    std::vector<int> free_slots;
+    for (size_t k = 0; k < nslots; ++k) free_slots.push_back(static_cast<int>(k));
+    std::deque<Done> finished;
+    size_t next_block = 0;
+    auto worker = [&] {
+        for (;;) {
+            size_t block;
+            int slot;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                if (next_block >= count) return;
+                block = next_block++;
+                cv_slot.wait(lk, [&] { return !free_slots.empty(); });
+                slot = free_slots.back();
+                free_slots.pop_back();
+            }
+            Done d{block, slot, 0, 0, DK_OK};
+            d.rc = decode_block_stream(model_id, in[block], in_len[block], n[block], reinterpret_cast<uint8_t *>(ctx->slots[slot].h), &d.origin,
+                                       &d.single);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                finished.push_back(d);
+            }
+            cv_done.notify_one();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (size_t w = 0; w < workers; ++w) pool.emplace_back(worker);
+    int rc = DK_OK;
+    size_t bad_block = 0;
+    hipStream_t st = ctx->stream;
+    for (size_t done_count = 0; done_count < count; ++done_count) {
+        Done d;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_done.wait(lk, [&] { return !finished.empty(); });
+            d = finished.front();
+            finished.pop_front();
+        }
+        if (rc == DK_OK && d.rc != DK_OK) { rc = d.rc; bad_block = d.block; }
+        if (rc == DK_OK) {
+            ctx->ws_reset();
+            const size_t nb = n[d.block];
+            uint8_t *d_bwt = ctx->ws_alloc<uint8_t>(nb);
+            hipError_t e = d_bwt ? hipMemcpyAsync(d_bwt, ctx->slots[d.slot].h, nb, hipMemcpyHostToDevice, st) : hipErrorOutOfMemory;
+            if (e == hipSuccess) e = hipStreamSynchronize(st);  // the slot may be refilled from here on
+            if (e != hipSuccess) { rc = ctx->fail(DK_E_HIP, "batch decode upload: %s", hipGetErrorString(e)); }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                free_slots.push_back(d.slot);
+            }
+            cv_slot.notify_one();
+            if (rc == DK_OK) {
+                if (d.single) {
+                    if (hipMemcpyAsync(d_out[d.block], d_bwt, nb, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = ctx->fail(DK_E_HIP, "copy failed");
+                } else if (d.origin >= nb) {
+                    rc = ctx->fail(DK_E_STREAM, "decoded origin %u is outside block %zu", d.origin, d.block);
+                } else {
+                    rc = bwt_inverse_device(ctx, d_bwt, nb, d.origin, d_out[d.block]);
+                }
+            }
+        } else {
+            std::lock_guard<std::mutex> lk(mu);
+            free_slots.push_back(d.slot);
+            cv_slot.notify_one();
+        }
+    }
+    for (auto &th : pool) th.join();
+    (void)hipStreamSynchronize(st);
+    ctx->stats.ms_total = t.ms();
+    if (rc != DK_OK && ctx->err.empty()) return ctx->fail(rc, "stream of block %zu does not decode (%d)", bad_block, rc);
+    return rc;
+}
+
 // ---- host-pointer entry points: stage in, run the device path, stage out ---------------------------------------------
 int dk_suffix_array(dk_ctx *ctx, const uint8_t *in, size_t n, uint32_t *sa_out) {
     DK_TRY(begin_call(ctx));

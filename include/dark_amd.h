@@ -95,6 +95,9 @@ int dk_dev_block_encode(dk_ctx *ctx, int model_id, const uint8_t *d_in, size_t n
  * Encoder::new, src/block/dc.rs:30-37,53).  out[i] / out_len[i] are exactly what dk_dev_block_encode gives for block i. */
 int dk_dev_batch_encode(dk_ctx *ctx, int model_id, size_t count, const uint8_t *const *d_in, const size_t *n,
                         uint8_t *const *out, const size_t *out_cap, size_t *out_len, int host_threads);
+/* inverse of dk_dev_batch_encode: host threads decode the streams while the GPU inverts the BWTs that are ready */
+int dk_dev_batch_decode(dk_ctx *ctx, int model_id, size_t count, const uint8_t *const *in, const size_t *in_len, const size_t *n,
+                        uint8_t *const *d_out, int host_threads);
 /* whole inverse path from a coded stream in host memory to a device-resident block */
 int dk_dev_block_decode(dk_ctx *ctx, int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *d_out);
 

@@ -245,5 +245,12 @@ def test_batch_encode_matches_single(ctx, orc):
     streams = ctx.dev_batch_encode("dark", d_blocks, [len(b) for b in blocks], host_threads=3)
     for b, s in zip(blocks, streams):
         assert s.tobytes() == orc.block_dc_encode("dark", b)
+    d_outs = [torch.empty(len(b), dtype=torch.uint8, device="cuda") for b in blocks]
+    ctx.dev_batch_decode("dark", streams, [len(b) for b in blocks], d_outs, host_threads=4)
+    for b, o in zip(blocks, d_outs):
+        assert o.cpu().numpy().tobytes() == b.tobytes()
     streams = ctx.dev_batch_encode("ybs", d_blocks[:2], [len(b) for b in blocks[:2]], host_threads=8)
     assert streams[1].tobytes() == ctx.block_encode("ybs", blocks[1])
+    with pytest.raises(dark_amd.DarkError):  # a stream cut short fails its block and the call, it does not hang the pool
+        ctx.dev_batch_decode("dark", [streams[0][:40]] + list(streams), [len(blocks[0])] + [len(b) for b in blocks[:2]],
+                             [d_outs[0]] + d_outs[:2], host_threads=2)
