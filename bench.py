@@ -143,11 +143,14 @@ def main():
         d_out = torch.empty(n, dtype=torch.uint8, device=dev)
         try:
             ctx.dev_block_decode(args.model, stream, n, d_out)
+            ctx.stats_reset()
+            ctx.set_profiling(True)
             barrier()
             t1 = time.perf_counter()
             for _ in range(args.steps):
                 ctx.dev_block_decode(args.model, stream, n, d_out)
             barrier()
+            ctx.set_profiling(False)
             dt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
             if world > 1:
                 dist.all_reduce(dt, op=dist.ReduceOp.MAX)
@@ -249,6 +252,7 @@ def main():
         }
         if dstats:
             result["decode_stage_ms"] = {kk: round(dstats[kk], 3) for kk in ("ms_entropy", "ms_h2d", "ms_ibwt", "ms_total")}
+            result["decode_kernel_ms_per_step"] = {kk: round(v["ms"] / k, 3) for kk, v in sorted(dstats["kernels"].items(), key=lambda x: -x[1]["ms"])}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import orc  # the checker, timed as the CPU baseline (never the thing measured above)
             sample = block[:min(n, args.cpu_sample)]
