@@ -228,14 +228,33 @@ __global__ __launch_bounds__(256) void k_ibwt_emit(const uint8_t *__restrict__ b
     const uint32_t d = dist_to_end[s];
     if (d > n) { *bad = 1; return; }  // not on the text cycle (corrupt input)
     uint32_t k = n - d;  // text offset of the first symbol this splitter emits
+    // bytes are gathered into a 64-bit word and leave as one aligned 8-byte store (single bytes only at the ragged ends)
+    const bool wide = (reinterpret_cast<uintptr_t>(out) & 7) == 0;
+    uint64_t acc = 0;
+    uint32_t have = 0;
+    auto put = [&](uint8_t b) {
+        if (wide && (have > 0 || (k & 7u) == 0)) {
+            acc |= static_cast<uint64_t>(b) << (8 * have);
+            ++have;
+            ++k;
+            if (have == 8) {
+                *reinterpret_cast<uint64_t *>(out + k - 8) = acc;
+                acc = 0;
+                have = 0;
+            }
+        } else {
+            out[k++] = b;
+        }
+    };
     for (;;) {
         const uint32_t p = psi[cur];
-        if (p == IB_END) { if (k < n) out[k] = bwt[origin]; else *bad = 1; break; }
+        if (p == IB_END) { if (k < n) put(bwt[origin]); else *bad = 1; break; }
         if (k >= n) { *bad = 1; break; }
-        out[k++] = bwt[p];
+        put(bwt[p]);
         if (is_splitter(p, S, origin)) break;
         cur = p;
     }
+    for (uint32_t jj = 0; jj < have; ++jj) out[k - have + jj] = static_cast<uint8_t>(acc >> (8 * jj));
 }
 
 }  // namespace
