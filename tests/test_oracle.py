@@ -129,3 +129,37 @@ def test_saca_storage_words(orc):
     assert L.orc_saca_storage_words(768771) == 768771 + 256 + 768771 // 4
     assert L.orc_saca_storage_words(1000) == 1000 + 256 + 500
     assert L.orc_saca_storage_words(10**6) == 10**6 + 256 + 250000
+
+
+def test_dc_distances_agree_with_dark_c_analogue(orc):
+    # /root/reference/etc/dark-c/src/ptax.cpp:61-111 (Ptax::Perform) is the same author's earlier DC: at every run start `cp` of a
+    # symbol whose previous run ended at `lp` it stores r[lp] = cp - lp - arm - 1, `arm` being the symbol's move-to-front rank.
+    # It keeps different side information (per-symbol run counts instead of a final sweep), but wherever it defines a distance
+    # the restated compress::bwt::dc::encode must agree.  The analogue is restated here in plain Python (explicit MTF list).
+    def analogue(data):
+        n = len(data)
+        r = {}
+        last, mtf, cp = {}, [], 0
+        while cp < n:
+            cs = data[cp]
+            if cs in last:
+                arm = mtf.index(cs)
+                r[last[cs]] = cp - last[cs] - arm - 1
+                mtf.remove(cs)
+            mtf.insert(0, cs)
+            while cp < n and data[cp] == cs:
+                cp += 1
+            last[cs] = cp - 1
+        return r, last, mtf
+
+    for t in seeded_inputs(seed=71, count=40, max_n=1500):
+        data = t.tolist()
+        r, last, mtf = analogue(data)
+        dc = orc.dc_encode(t)
+        sparse = dc["sparse"]
+        n = len(t)
+        for pos, d in r.items():
+            assert sparse[pos] == d, (pos, d, sparse[pos])
+        # every other entry the oracle holds is the final sweep: one per symbol, at its last position, n - last - rank - 1
+        extra = {int(p): int(sparse[p]) for p in np.flatnonzero(sparse != n) if int(p) not in r}
+        assert extra == {last[s]: n - last[s] - rank - 1 for rank, s in enumerate(mtf)}
