@@ -319,6 +319,206 @@ __global__ __launch_bounds__(RS_BLOCK) void k_radix_scatter(const uint64_t *__re
     }
 }
 
+
+// ---- chunked single-kernel passes (DK_SORT=chunked) -------------------------------------------------------------------
+// The tiles are cut into RS_NCH = 8 contiguous chunks, one per XCD group (blocks b with equal b mod 8; observed placement, speed
+// only).  Inside a chunk tiles are handed out by a ticket and find their offsets by decoupled look-back over the chunk's earlier
+// tiles only; what precedes the chunk comes from per-chunk digit histograms H[chunk][digit], which the previous pass accumulates
+// while it scatters (every element knows its destination, hence its chunk in the next pass) -- so a pass is ONE kernel: no
+// per-pass histogram read, no scan kernels, and neighbouring output runs still meet in one XCD's L2.
+constexpr int RS_NCH = 8;
+
+struct ChunkGeom {
+    uint32_t ntiles, tiles_per_chunk;
+    uint64_t div_magic;  // ceil(2^40 / tiles_per_chunk): (x * magic) >> 40 == x / tiles_per_chunk for x < 2^20
+};
+__device__ __forceinline__ uint32_t chunk_of_tile(uint32_t tile, const ChunkGeom &g) {
+    return static_cast<uint32_t>((static_cast<uint64_t>(tile) * g.div_magic) >> 40);
+}
+
+// H[chunk][digit] of the input arrangement for the first pass
+__global__ __launch_bounds__(RS_BLOCK) void k_chunk_hist(const uint64_t *__restrict__ keys, size_t n, int shift, ChunkGeom g,
+                                                          uint32_t *__restrict__ H) {
+    __shared__ uint32_t h[RS_HCOPIES][256];
+    const int tid = threadIdx.x;
+    const uint32_t c = blockIdx.x % RS_NCH, lb = blockIdx.x / RS_NCH, nb = gridDim.x / RS_NCH;
+#pragma unroll
+    for (int k = 0; k < RS_HCOPIES; ++k) h[k][tid] = 0;
+    __syncthreads();
+    uint32_t *mine = h[tid & (RS_HCOPIES - 1)];
+    const uint32_t t0 = c * g.tiles_per_chunk;
+    const uint32_t t1 = t0 + g.tiles_per_chunk < g.ntiles ? t0 + g.tiles_per_chunk : g.ntiles;
+    for (uint32_t t = t0 + lb; t < t1; t += nb) {
+        const size_t base = static_cast<size_t>(t) * RS_TILE;
+#pragma unroll
+        for (int k = 0; k < RS_KPT; ++k) {
+            const size_t i = base + static_cast<size_t>(k) * RS_BLOCK + tid;
+            if (i < n) atomicAdd(&mine[digit_of(keys[i], shift)], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < RS_HCOPIES; ++k) sum += h[k][tid];
+    if (sum) atomicAdd(&H[c * 256 + tid], sum);
+}
+
+// ctrl[0..7] = tickets per chunk, ctrl[8] = error word; status rows follow at ctrl + 64
+__global__ __launch_bounds__(RS_BLOCK) void k_radix_chunked(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                             uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n, int shift,
+                                                             int next_shift, ChunkGeom g, const uint32_t *__restrict__ H_cur,
+                                                             uint32_t *__restrict__ H_next, uint32_t *__restrict__ ctrl) {
+    __shared__ uint64_t s_keys[RS_TILE];
+    __shared__ uint32_t s_cnt[RS_WAVES][256];
+    __shared__ uint32_t s_start[256];
+    __shared__ uint32_t s_gbase[256];
+    __shared__ uint32_t s_cbase[256];            // global start of (this chunk, digit)
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_hnext[RS_NCH][256];    // next pass: counts per (destination chunk, next digit), flushed once
+    __shared__ uint32_t s_tmp[RS_WAVES + 1];
+    __shared__ uint32_t s_ticket;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t c = blockIdx.x % RS_NCH;
+    uint32_t *status = ctrl + 64;
+    const uint32_t t0 = c * g.tiles_per_chunk;
+    if (t0 >= g.ntiles) return;
+    const uint32_t tiles_here = (t0 + g.tiles_per_chunk < g.ntiles ? t0 + g.tiles_per_chunk : g.ntiles) - t0;
+    {   // where this chunk's share of every digit starts
+        uint32_t tot = 0, before = 0;
+#pragma unroll
+        for (int cc = 0; cc < RS_NCH; ++cc) {
+            const uint32_t v = H_cur[cc * 256 + tid];
+            if (static_cast<uint32_t>(cc) < c) before += v;
+            tot += v;
+        }
+        s_cbase[tid] = block_excl_sum<RS_WAVES>(tot, s_tmp, nullptr) + before;
+#pragma unroll
+        for (int cc = 0; cc < RS_NCH; ++cc) s_hnext[cc][tid] = 0;
+    }
+    const uint64_t lt = lanemask_lt(lane);
+    const uint32_t wbase = static_cast<uint32_t>(wave) * (64 * RS_KPT);
+    for (;;) {
+        __syncthreads();  // previous tile fully written out; LDS reusable
+        if (tid == 0) s_ticket = atomicAdd(&ctrl[c], 1u);
+        for (int i = tid; i < RS_WAVES * 256; i += RS_BLOCK) (&s_cnt[0][0])[i] = 0;
+        s_hist[tid] = 0;
+        __syncthreads();
+        const uint32_t ticket = s_ticket;
+        if (ticket >= tiles_here) break;
+        const uint32_t tile = t0 + ticket;
+        const size_t tile_base = static_cast<size_t>(tile) * RS_TILE;
+        const size_t left = n - tile_base;
+        const uint32_t valid = left < static_cast<size_t>(RS_TILE) ? static_cast<uint32_t>(left) : RS_TILE;
+        uint64_t key[RS_KPT];
+        uint32_t val[RS_KPT];
+#pragma unroll
+        for (int k = 0; k < RS_KPT; ++k) {
+            const uint32_t li = wbase + k * 64 + lane;
+            if (li < valid) {
+                key[k] = kin[tile_base + li];
+                val[k] = vin[tile_base + li];
+                atomicAdd(&s_hist[digit_of(key[k], shift)], 1u);
+            } else {
+                key[k] = ~0ull;
+                val[k] = 0;
+            }
+        }
+        __syncthreads();
+        const uint32_t my_cnt = s_hist[tid];
+        uint32_t *mine = status + static_cast<size_t>(tile) * 256 + tid;
+        __hip_atomic_store(mine, (ticket == 0 ? ST_INCL : ST_LOCAL) | my_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // look back over the earlier tiles of THIS chunk only (its first tile publishes INCL at once), BEFORE the long ranking:
+        // the sooner the inclusive word is out, the shorter everybody else's walk
+        uint32_t excl = 0;
+        if (ticket != 0) {
+            const uint32_t *look = mine - 256;
+            uint32_t spins = 0;
+            for (;;) {
+                const uint32_t v = __hip_atomic_load(look, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 30) == 0) {
+                    if (++spins > RS_SPIN_LIMIT) { ctrl[8] = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                excl += v & ST_MASK;
+                if (v & ST_INCL) break;
+                look -= 256;
+            }
+            __hip_atomic_store(mine, ST_INCL | (excl + my_cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+
+        uint32_t rnk[RS_KPT];
+#pragma unroll
+        for (int k = 0; k < RS_KPT; ++k) {
+            const uint32_t d = digit_of(key[k], shift);
+            uint64_t same = ~0ull;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                same &= bit ? bal : ~bal;
+            }
+            const uint32_t before = static_cast<uint32_t>(__popcll(same & lt));
+            const uint32_t old = s_cnt[wave][d];
+            __builtin_amdgcn_wave_barrier();
+            if (before == 0) s_cnt[wave][d] = old + static_cast<uint32_t>(__popcll(same));
+            __builtin_amdgcn_wave_barrier();
+            rnk[k] = old + before;
+        }
+        __syncthreads();
+        {
+            const int d = tid;
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < RS_WAVES; ++w) {
+                const uint32_t cc = s_cnt[w][d];
+                s_cnt[w][d] = run;
+                run += cc;
+            }
+            const uint32_t start = block_excl_sum<RS_WAVES>(run, s_tmp, nullptr);
+            s_start[d] = start;
+            s_gbase[d] = s_cbase[d] + excl - start;
+        }
+        __syncthreads();
+        uint32_t pos[RS_KPT];
+#pragma unroll
+        for (int k = 0; k < RS_KPT; ++k) {
+            const uint32_t d = digit_of(key[k], shift);
+            pos[k] = s_start[d] + s_cnt[wave][d] + rnk[k];
+            s_keys[pos[k]] = key[k];
+        }
+        __syncthreads();
+        uint32_t gi[RS_KPT];
+#pragma unroll
+        for (int k = 0; k < RS_KPT; ++k) {
+            const uint32_t p = k * RS_BLOCK + tid;
+            const uint64_t kk = s_keys[p];
+            gi[k] = s_gbase[digit_of(kk, shift)] + p;
+            if (p < valid) {
+                kout[gi[k]] = kk;
+                if (next_shift >= 0) atomicAdd(&s_hnext[chunk_of_tile(gi[k] / RS_TILE, g)][digit_of(kk, next_shift)], 1u);
+            }
+        }
+        __syncthreads();
+        uint32_t *s_vals = reinterpret_cast<uint32_t *>(s_keys);
+#pragma unroll
+        for (int k = 0; k < RS_KPT; ++k) s_vals[pos[k]] = val[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RS_KPT; ++k) {
+            const uint32_t p = k * RS_BLOCK + tid;
+            if (p < valid) vout[gi[k]] = s_vals[p];
+        }
+    }
+    if (next_shift >= 0) {
+#pragma unroll
+        for (int cc = 0; cc < RS_NCH; ++cc) {
+            const uint32_t v = s_hnext[cc][tid];
+            if (v) atomicAdd(&H_next[cc * 256 + tid], v);
+        }
+    }
+}
+
 }  // namespace
 
 // Sorts `count` pairs on key bits [begin_bit, end_bit).  keys/vals are the input buffers, *_alt equally sized scratch;
@@ -399,15 +599,57 @@ static int sort_pairs_onesweep(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt
     return DK_OK;
 }
 
+static int sort_pairs_chunked(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
+                              int begin_bit, int end_bit) {
+    const size_t ntiles = div_up(count, RS_TILE);
+    const int npasses = (end_bit - begin_bit + 7) / 8;
+    ChunkGeom g;
+    g.ntiles = static_cast<uint32_t>(ntiles);
+    g.tiles_per_chunk = static_cast<uint32_t>(div_up(ntiles, RS_NCH));
+    g.div_magic = ((1ull << 40) + g.tiles_per_chunk - 1) / g.tiles_per_chunk;
+    const size_t mark = ctx->ws_mark();
+    uint32_t *H = ctx->ws_alloc<uint32_t>(static_cast<size_t>(npasses + 1) * RS_NCH * 256);
+    uint32_t *ctrl = ctx->ws_alloc<uint32_t>(64 + ntiles * 256);
+    if (!H || !ctrl) return DK_E_NOMEM;
+    uint32_t *d_err = ctx->d_mail + 12;
+    hipStream_t st = ctx->stream;
+    DK_HIP(ctx, hipMemsetAsync(H, 0, static_cast<size_t>(npasses + 1) * RS_NCH * 256 * sizeof(uint32_t), st));
+    const size_t grid = RS_NCH * std::min<size_t>(div_up(ntiles, RS_NCH), 160);
+    {
+        LaunchScope ls(ctx, K_RADIX_HIST, 8.0 * count);
+        k_chunk_hist<<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(keys, count, begin_bit, g, H);
+    }
+    for (int p = 0; p < npasses; ++p) {
+        DK_HIP(ctx, hipMemsetAsync(ctrl, 0, (64 + ntiles * 256) * sizeof(uint32_t), st));
+        {
+            LaunchScope ls(ctx, K_RADIX_SCATTER, 24.0 * count);
+            k_radix_chunked<<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(keys, vals, keys_alt, vals_alt, count, begin_bit + 8 * p,
+                                                                   p + 1 < npasses ? begin_bit + 8 * (p + 1) : -1, g, H + p * RS_NCH * 256,
+                                                                   H + (p + 1) * RS_NCH * 256, ctrl);
+        }
+        DK_HIP(ctx, hipGetLastError());
+        k_radix_fold_err<<<dim3(1), dim3(1), 0, st>>>(ctrl + 8, d_err);
+        std::swap(keys, keys_alt);
+        std::swap(vals, vals_alt);
+        ctx->stats.sort_passes += 1;
+        ctx->stats.sorted_elements += count;
+    }
+    ctx->ws_release(mark);
+    return DK_OK;
+}
+
 int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
                int begin_bit, int end_bit) {
     if (count <= 1 || end_bit <= begin_bit) return DK_OK;
     if (count > 0xFFFFFFFEull) return ctx->fail(DK_E_ARG, "sort_pairs: count too large");
     // default: three-phase passes with the XCD-aware tile order (measured 4.2 TB/s on the scatter); DK_SORT=onesweep selects the
     // single-kernel look-back variant (no per-pass histogram, but ticket order defeats the XCD locality: 2.2 TB/s)
-    static const bool onesweep = [] { const char *e = getenv("DK_SORT"); return e && std::string(e) == "onesweep"; }();
-    if (!onesweep || count >= (1ull << 30)) return sort_pairs_classic(ctx, keys, keys_alt, vals, vals_alt, count, begin_bit, end_bit);
-    return sort_pairs_onesweep(ctx, keys, keys_alt, vals, vals_alt, count, begin_bit, end_bit);
+    static const std::string mode = [] { const char *e = getenv("DK_SORT"); return std::string(e ? e : ""); }();
+    if (count < (1ull << 30)) {
+        if (mode == "onesweep") return sort_pairs_onesweep(ctx, keys, keys_alt, vals, vals_alt, count, begin_bit, end_bit);
+        if (mode == "chunked") return sort_pairs_chunked(ctx, keys, keys_alt, vals, vals_alt, count, begin_bit, end_bit);
+    }
+    return sort_pairs_classic(ctx, keys, keys_alt, vals, vals_alt, count, begin_bit, end_bit);
 }
 
 // ---- bucketed scatter: dst[idx[i]] = val[i] for a huge, random idx ---------------------------------------------------

@@ -55,6 +55,6 @@ def test_two_thread_entropy_is_bit_exact():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"DK_SORT": "onesweep"}, {"DK_BUCKETED": "0"}, {"DK_XCD": "0"}])
+@pytest.mark.parametrize("env", [{"DK_SORT": "onesweep"}, {"DK_SORT": "chunked"}, {"DK_BUCKETED": "0"}, {"DK_XCD": "0"}])
 def test_gpu_variants_match_oracle(env):
     _run(GPU_SNIPPET, env)
