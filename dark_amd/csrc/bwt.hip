@@ -311,20 +311,24 @@ int bwt_inverse_device(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t ori
         k_ibwt_walk<<<dim3(div_up(nsplit, 256)), dim3(256), 0, st>>>(psi, static_cast<uint32_t>(n), origin, S, nreg, nsplit, nxt, acc);
     }
     DK_HIP(ctx, hipGetLastError());
+    // Pointer jumping halves every chain per step: ceil(log2(nsplit)) + 1 steps finish any single path through the splitters.
+    // They are enqueued back to back (no host round trip per step); only the last one reports whether something is still
+    // unresolved, which can only mean a cycle (corrupt input).
     uint32_t *d_pending = ctx->d_mail + 10;
-    for (int it = 0; it < 40; ++it) {
-        DK_HIP(ctx, hipMemsetAsync(d_pending, 0, sizeof(uint32_t), st));
+    const int steps = static_cast<int>(ceil_log2_u64(nsplit)) + 1;
+    for (int it = 0; it < steps; ++it) {
+        if (it == steps - 1) DK_HIP(ctx, hipMemsetAsync(d_pending, 0, sizeof(uint32_t), st));
         {
             LaunchScope ls(ctx, K_IBWT_RANK, 24.0 * nsplit);
             k_ibwt_jump<<<dim3(div_up(nsplit, 256)), dim3(256), 0, st>>>(nxt, acc, nxt_alt, acc_alt, nsplit, d_pending);
         }
         std::swap(nxt, nxt_alt);
         std::swap(acc, acc_alt);
-        DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 10, d_pending, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        DK_HIP(ctx, hipStreamSynchronize(st));
-        if (ctx->h_mail[10] == 0) break;
-        if (it == 39) return ctx->fail(DK_E_STREAM, "bwt_inverse: successor table has a cycle (corrupt input)");
     }
+    DK_HIP(ctx, hipGetLastError());
+    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 10, d_pending, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    DK_HIP(ctx, hipStreamSynchronize(st));
+    if (ctx->h_mail[10] != 0) return ctx->fail(DK_E_STREAM, "bwt_inverse: successor table has a cycle (corrupt input)");
     uint32_t *d_bad = ctx->d_mail + 11;
     DK_HIP(ctx, hipMemsetAsync(d_bad, 0, sizeof(uint32_t), st));
     {
