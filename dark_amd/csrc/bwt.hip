@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_ibwt_scan_c(uint32_t *__restrict__ tile
 // its class (it is the suffix consisting of the last text symbol alone, the smallest of its class).
 __global__ __launch_bounds__(IB_BLOCK) void k_ibwt_lf(const uint8_t *__restrict__ bwt, size_t n, uint32_t origin,
                                                        const uint32_t *__restrict__ tile_offs, const uint32_t *__restrict__ class_start,
-                                                       uint32_t *__restrict__ psi) {
+                                                       uint64_t *__restrict__ psi) {
     __shared__ uint32_t s_cnt[IB_WAVES][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t tile_base = static_cast<size_t>(blockIdx.x) * IB_TILE;
@@ -157,8 +157,9 @@ __global__ __launch_bounds__(IB_BLOCK) void k_ibwt_lf(const uint8_t *__restrict_
         uint32_t dest = s_cnt[wave][sym[k]] + rnk[k];
         if (i == origin) dest = c0_start;
         else if (sym[k] == c0 && i < origin) dest += 1;
-        // the origin element has no successor: following it ends the text (the reference stores table[..] = 0 there)
-        psi[dest] = i == origin ? IB_END : static_cast<uint32_t>(i);
+        // the origin element has no successor: following it ends the text (the reference stores table[..] = 0 there).
+        // The entry also carries the symbol the step emits (L[i]), so that a walk makes ONE dependent random load per step.
+        psi[dest] = (static_cast<uint64_t>(sym[k]) << 32) | (i == origin ? IB_END : static_cast<uint32_t>(i));
     }
 }
 
@@ -171,7 +172,7 @@ __device__ __forceinline__ uint32_t splitter_id(uint32_t p, uint32_t S, uint32_t
 
 // Text step k visits position cur_k: cur_0 = origin, cur_{k+1} = psi[cur_k]... with the reference's convention the
 // text symbol k is L[psi[cur_k]], and the last symbol is L[origin] when psi hits END.
-__global__ __launch_bounds__(256) void k_ibwt_walk(const uint32_t *__restrict__ psi, uint32_t n, uint32_t origin, uint32_t S,
+__global__ __launch_bounds__(256) void k_ibwt_walk(const uint64_t *__restrict__ psi, uint32_t n, uint32_t origin, uint32_t S,
                                                     uint32_t nreg, uint32_t nsplit, uint32_t *__restrict__ nxt,
                                                     uint32_t *__restrict__ len) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void k_ibwt_walk(const uint32_t *__restrict__ 
     }
     uint32_t steps = 0, to = IB_END;
     for (;;) {
-        const uint32_t p = psi[cur];
+        const uint32_t p = static_cast<uint32_t>(psi[cur]);
         ++steps;  // this step emits one text symbol
         if (p == IB_END) break;
         if (is_splitter(p, S, origin)) { to = splitter_id(p, S, origin, nreg); break; }
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void k_ibwt_jump(const uint32_t *__restrict__ 
     if (to2 != IB_END) *pending = 1;
 }
 
-__global__ __launch_bounds__(256) void k_ibwt_emit(const uint8_t *__restrict__ bwt, const uint32_t *__restrict__ psi, uint32_t n,
+__global__ __launch_bounds__(256) void k_ibwt_emit(const uint8_t *__restrict__ bwt, const uint64_t *__restrict__ psi, uint32_t n,
                                                     uint32_t origin, uint32_t S, uint32_t nreg, uint32_t nsplit,
                                                     const uint32_t *__restrict__ dist_to_end, uint8_t *__restrict__ out,
                                                     uint32_t *__restrict__ bad) {
@@ -247,10 +248,12 @@ __global__ __launch_bounds__(256) void k_ibwt_emit(const uint8_t *__restrict__ b
         }
     };
     for (;;) {
-        const uint32_t p = psi[cur];
-        if (p == IB_END) { if (k < n) put(bwt[origin]); else *bad = 1; break; }
+        const uint64_t e = psi[cur];
+        const uint32_t p = static_cast<uint32_t>(e);
+        const uint8_t symbol = static_cast<uint8_t>(e >> 32);  // = L[p], or L[origin] on the terminal entry
+        if (p == IB_END) { if (k < n) put(symbol); else *bad = 1; break; }
         if (k >= n) { *bad = 1; break; }
-        put(bwt[p]);
+        put(symbol);
         if (is_splitter(p, S, origin)) break;
         cur = p;
     }
@@ -285,7 +288,7 @@ int bwt_inverse_device(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t ori
     uint32_t *tile_hist = ctx->ws_alloc<uint32_t>(ntiles * 256);
     uint32_t *chunk_sum = ctx->ws_alloc<uint32_t>(nchunks * 256);
     uint32_t *class_start = ctx->ws_alloc<uint32_t>(256);
-    uint32_t *psi = ctx->ws_alloc<uint32_t>(n);
+    uint64_t *psi = ctx->ws_alloc<uint64_t>(n);
     if (!tile_hist || !chunk_sum || !class_start || !psi) return DK_E_NOMEM;
     {
         LaunchScope ls(ctx, K_IBWT_HIST, 1.0 * n);
