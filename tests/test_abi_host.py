@@ -147,3 +147,22 @@ def test_bitcoder_matches_oracle(orc, vectors):
     s = entropy.encode_bits(bits, flat)
     assert s == orc.bitcoder_encode(bits, flat)
     assert (entropy.decode_bits(s, flat) == bits).all()
+
+
+def test_property_model_streams(orc):
+    # hypothesis: arbitrary (distance, symbol) streams -- the product's host coder and the oracle must produce the same bytes,
+    # and decoding must give the stream back, for every model within its documented distance range
+    from hypothesis import given, settings, strategies as st
+
+    limits = {"dark": 2**31 - 2, "exp": 2**24 - 1, "ybs": 2**29 - 1, "simple": 2**24 + 254}
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.sampled_from(MODELS), st.lists(st.tuples(st.integers(0, 31), st.integers(0, 2**31), st.integers(0, 255)), min_size=0, max_size=300))
+    def check(m, items):
+        d = np.array([min((1 << b) - 1 + (r % (1 << b) if b else 0), limits[m]) for b, r, _ in items], dtype=np.uint32)
+        sym = np.array([s for _, _, s in items], dtype=np.uint8)
+        got = model.encode(m, d, sym)
+        assert got == orc.model_encode(m, d, sym)
+        assert (model.decode(m, got, sym) == d).all()
+
+    check()
