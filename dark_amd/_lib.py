@@ -18,7 +18,7 @@ class Stats(C.Structure):
     _fields_ = [("ms_h2d", C.c_double), ("ms_sa", C.c_double), ("ms_bwt", C.c_double), ("ms_dc", C.c_double),
                 ("ms_d2h", C.c_double), ("ms_entropy", C.c_double), ("ms_ibwt", C.c_double), ("ms_total", C.c_double),
                 ("rounds", C.c_uint32), ("sort_passes", C.c_uint32), ("sorted_elements", C.c_uint64),
-                ("dc_runs", C.c_uint64),
+                ("dc_runs", C.c_uint64), ("entropy_threads", C.c_uint32), ("reserved0", C.c_uint32),
                 ("kernel_launches", C.c_uint32 * NUM_KERNEL_SLOTS), ("kernel_ms", C.c_double * NUM_KERNEL_SLOTS),
                 ("kernel_bytes", C.c_double * NUM_KERNEL_SLOTS)]
 

@@ -116,6 +116,7 @@ int block_encode_common(dk_ctx *ctx, int model_id, const uint8_t *d_text, size_t
     s.n = n; s.init = fr.init; s.dist = fr.dist; s.sym = fr.sym; s.rank = fr.rank; s.run_end = fr.run_end; s.m = fr.m; s.origin = fr.origin;
     int rc = encode_block_stream(model_id, s, out, out_cap, out_len);
     ctx->stats.ms_entropy = t.ms();
+    ctx->stats.entropy_threads = static_cast<uint32_t>(dk::last_entropy_threads());
     if (rc == DK_E_CAPACITY) return ctx->fail(rc, "output buffer of %zu bytes is too small", out_cap);
     if (rc) return ctx->fail(rc, "entropy stage failed (%d)", rc);
     return DK_OK;
@@ -316,7 +317,7 @@ int dk_dev_batch_encode(dk_ctx *ctx, int model_id, size_t count, const uint8_t *
             DcStream s;
             s.n = n[job.block]; s.init = job.fr.init; s.dist = job.fr.dist; s.sym = job.fr.sym; s.rank = job.fr.rank;
             s.run_end = job.fr.run_end; s.m = job.fr.m; s.origin = job.fr.origin;
-            rcs[job.block] = encode_block_stream(model_id, s, out[job.block], out_cap[job.block], &out_len[job.block]);
+            rcs[job.block] = encode_block_stream(model_id, s, out[job.block], out_cap[job.block], &out_len[job.block], 1);
             {
                 std::lock_guard<std::mutex> lk(mu);
                 free_slots.push_back(job.slot);

@@ -3,9 +3,16 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <thread>
 #include <vector>
+#if defined(__linux__)
+#include <pthread.h>
+#include <sched.h>
+#endif
 
 namespace dk {
 
@@ -40,10 +47,9 @@ inline void DarkModel::adapt(PerSymbol &c, uint32_t dist, int log_diff) {  // da
 }
 
 template <class E>
-bool DarkModel::encode(uint32_t dist, uint8_t symbol, E &e) {  // dark.rs:180-232
+bool DarkModel::encode_exponent(uint32_t dist, uint8_t symbol, E &e) {  // dark.rs:180-214,229-231
     if (dist >= 0x7FFFFFFFu) return false;  // log would reach 32: freq_mantissa has 32 rows
-    const uint32_t v = dist + 1;
-    const unsigned log = bit_length(v);
+    const unsigned log = bit_length(dist + 1);
     PerSymbol &c = sym_[symbol];
     const unsigned avg_log = std::min(kMaxLogContext, bit_length(static_cast<uint32_t>(c.avg_dist)));
     {
@@ -66,8 +72,18 @@ bool DarkModel::encode(uint32_t dist, uint8_t symbol, E &e) {  // dark.rs:180-23
         gb[i].learn<2>(false);
     }
     last_token_ = token_of(log);
+    adapt(c, dist, static_cast<int>(log) - static_cast<int>(avg_log));
+    return true;
+}
+static_assert(kMaxLogCode == 8, "DarkModel::exponent_bits assumes MAX_LOG_CODE = 8");
+
+template <class E>
+bool DarkModel::encode_mantissa(uint32_t dist, E &e) {  // dark.rs:216-227
+    if (dist >= 0x7FFFFFFFu) return false;
+    const uint32_t v = dist + 1;
+    const unsigned log = bit_length(v);
     BinFreq *mc = mantissa_[log];
-    // mantissa below the leading one, MSB first: three adaptive bits, the rest through the never-updated 4th model (dark.rs:216-227)
+    // mantissa below the leading one, MSB first: three adaptive bits, the rest through the never-updated 4th model
     const unsigned modelled = log > kMaxBitContext ? kMaxBitContext : log - 1;
     for (unsigned i = 1; i <= modelled; ++i) {
         const bool bit = (v >> (log - i - 1)) & 1u;
@@ -77,8 +93,12 @@ bool DarkModel::encode(uint32_t dist, uint8_t symbol, E &e) {  // dark.rs:180-23
     const uint32_t flat = mc[kMaxBitContext].zero;
     for (unsigned i = kMaxBitContext + 1; i < log; ++i)
         if (!encode_bit_p(e, flat, (v >> (log - i - 1)) & 1u)) return false;
-    adapt(c, dist, static_cast<int>(log) - static_cast<int>(avg_log));
     return true;
+}
+
+template <class E>
+bool DarkModel::encode(uint32_t dist, uint8_t symbol, E &e) {  // dark.rs:180-232
+    return encode_exponent(dist, symbol, e) && encode_mantissa(dist, e);
 }
 
 bool DarkModel::decode(uint8_t symbol, Decoder &d, uint32_t &dist) {  // dark.rs:234-287
@@ -471,27 +491,28 @@ int with_model(int model_id, F &&f) {
 // ------------------------------------------------------------------------------------------------------------------
 class EventPipe {
 public:
-    static constexpr uint32_t kBatch = 1u << 12;  // events per batch (32 KiB: stays in the consumer's L2)
+    static constexpr uint32_t kBatch = 1u << 14;  // 16-bit units per batch (32 KiB: stays in the consumer's L2)
     static constexpr int kSlots = 16;
     static constexpr uint32_t kEnd = 0x80000000u;  // OR-ed into the count of the last batch
-    EventPipe() : buf_(new CodeEvent[static_cast<size_t>(kSlots) * kBatch]) {
+    EventPipe() : buf_(new uint16_t[static_cast<size_t>(kSlots) * kBatch]) {
         for (auto &c : ready_) c.store(0, std::memory_order_relaxed);
     }
-    CodeEvent *slot(int i) { return buf_.get() + static_cast<size_t>(i) * kBatch; }
-    // producer: wait until slot i has been consumed
-    void acquire_free(int i) {
+    uint16_t *slot(int i) { return buf_.get() + static_cast<size_t>(i) * kBatch; }
+    void acquire_free(int i) {  // producer: wait until slot i has been consumed
         unsigned spins = 0;
         while (ready_[i].load(std::memory_order_acquire) != 0) backoff(spins);
+        producer_spins += spins;
     }
     void publish(int i, uint32_t count_and_flags) { ready_[i].store(count_and_flags | kFull, std::memory_order_release); }
-    // consumer: wait until slot i is full; returns count | kEnd
-    uint32_t acquire_full(int i) {
+    uint32_t acquire_full(int i) {  // consumer: wait until slot i is full; returns count | kEnd
         unsigned spins = 0;
         uint32_t v;
         while ((v = ready_[i].load(std::memory_order_acquire)) == 0) backoff(spins);
+        consumer_spins += spins;
         return v & ~kFull;
     }
     void release(int i) { ready_[i].store(0, std::memory_order_release); }
+    uint64_t producer_spins = 0, consumer_spins = 0;  // pause iterations each side spent waiting (DK_TRACE)
 
 private:
     static constexpr uint32_t kFull = 0x40000000u;
@@ -505,7 +526,7 @@ private:
             std::this_thread::yield();
         }
     }
-    std::unique_ptr<CodeEvent[]> buf_;
+    std::unique_ptr<uint16_t[]> buf_;
     alignas(64) std::atomic<uint32_t> ready_[kSlots];
 };
 
@@ -539,15 +560,25 @@ int drain_pipe(EventPipe &pipe, uint8_t *out, size_t cap, size_t *out_len) {
     for (int slot = 0;; slot = (slot + 1) % EventPipe::kSlots) {
         const uint32_t v = pipe.acquire_full(slot);
         const uint32_t count = v & ~EventPipe::kEnd;
-        const CodeEvent *ev = pipe.slot(slot);
+        const uint16_t *ev = pipe.slot(slot);
         if (!err && len + 4 * static_cast<size_t>(count) + 12 > cap) err = DK_E_CAPACITY;  // keep draining so the producer can end
         if (!err) {
             uint8_t *p = out + len;
-            for (uint32_t k = 0; k < count; ++k) {
-                const CodeEvent e = ev[k];
+            for (uint32_t k = 0; k < count;) {
+                const uint32_t u = ev[k];
                 const uint32_t span = rs.hi - rs.low;
-                const uint32_t r = e.total ? span / e.total : span >> 12;
-                const int nb = r ? rs.narrow(r, e.from, e.to, p) : -1;
+                int nb;
+                if (u & 0x8000u) {  // binary decision under total 4096
+                    const uint32_t zero = u & 0x0FFFu, r = span >> 12;
+                    const bool one = (u & 0x4000u) != 0;
+                    nb = rs.narrow(r, one ? zero : 0u, one ? 4096u : zero, p);
+                    k += 1;
+                } else {
+                    const uint32_t to = ev[k + 1], total = ev[k + 2];
+                    const uint32_t r = span / total;
+                    nb = r ? rs.narrow(r, u, to, p) : -1;
+                    k += 3;
+                }
                 if (nb < 0) { err = DK_E_INTERNAL; break; }
                 p += nb;
             }
@@ -564,37 +595,222 @@ int drain_pipe(EventPipe &pipe, uint8_t *out, size_t cap, size_t *out_len) {
     return err;
 }
 
+// consumer side of the pipe when the consumer knows which kind of decision comes next
+class PipeReader {
+public:
+    explicit PipeReader(EventPipe &p) : pipe_(p) { next_batch(); }
+    // table decision (3 units, never split across batches) / binary decision (1 unit)
+    inline bool table(uint32_t &from, uint32_t &to, uint32_t &total) {
+        if (pos_ == count_ && !refill()) return false;
+        from = cur_[pos_]; to = cur_[pos_ + 1]; total = cur_[pos_ + 2];
+        pos_ += 3;
+        return true;
+    }
+    inline bool bit(uint32_t &zero, bool &one) {
+        if (pos_ == count_ && !refill()) return false;
+        const uint32_t u = cur_[pos_++];
+        zero = u & 0x0FFFu;
+        one = (u & 0x4000u) != 0;
+        return true;
+    }
+    void drain() {  // consume whatever the producer still sends, so that it can end
+        while (!last_) { pipe_.release(slot_); slot_ = (slot_ + 1) % EventPipe::kSlots; next_batch(); }
+        pipe_.release(slot_);
+    }
+
+private:
+    bool refill() {
+        while (pos_ == count_) {
+            if (last_) return false;  // the producer ended early (it failed)
+            pipe_.release(slot_);
+            slot_ = (slot_ + 1) % EventPipe::kSlots;
+            next_batch();
+        }
+        return true;
+    }
+    void next_batch() {
+        const uint32_t v = pipe_.acquire_full(slot_);
+        last_ = (v & EventPipe::kEnd) != 0;
+        count_ = v & ~EventPipe::kEnd;
+        cur_ = pipe_.slot(slot_);
+        pos_ = 0;
+    }
+    EventPipe &pipe_;
+    const uint16_t *cur_ = nullptr;
+    uint32_t pos_ = 0, count_ = 0;
+    int slot_ = 0;
+    bool last_ = false;
+};
+
+// The two halves of the dark model as write_stream sees them (see DarkModel::encode_exponent).
+struct DarkExponentSide {  // second thread: exponent decisions into the pipe
+    DarkModel &m;
+    bool encode(uint32_t dist, uint8_t symbol, EventSink &e) { return m.encode_exponent(dist, symbol, e); }
+};
+struct DarkCoderSide {  // calling thread: codes the piped exponent decisions, then models and codes the mantissa itself
+    DarkModel &m;
+    PipeReader &rd;
+    bool encode(uint32_t dist, uint8_t, Encoder &e) {
+        if (dist >= 0x7FFFFFFFu) return false;
+        uint32_t from, to, total;
+        if (!rd.table(from, to, total) || !e.put(total, from, to)) return false;
+        for (unsigned k = DarkModel::exponent_bits(dist); k; --k) {
+            uint32_t zero; bool one;
+            if (!rd.bit(zero, one) || !e.put_bit12(zero, one)) return false;
+        }
+        return m.encode_mantissa(dist, e);
+    }
+};
+
+#if defined(__linux__)
+// "0-7,128-135" -> {0..7, 128..135}
+std::vector<int> read_cpu_list(const std::string &path) {
+    std::vector<int> out;
+    FILE *f = std::fopen(path.c_str(), "r");
+    if (!f) return out;
+    char buf[4096];
+    if (std::fgets(buf, sizeof buf, f)) {
+        const char *p = buf;
+        while (*p && *p != '\n') {
+            char *end;
+            long a = std::strtol(p, &end, 10), b = a;
+            if (end == p) break;
+            if (*end == '-') { p = end + 1; b = std::strtol(p, &end, 10); }
+            for (long c = a; c <= b && out.size() < 4096; ++c) out.push_back(static_cast<int>(c));
+            p = (*end == ',') ? end + 1 : end;
+        }
+    }
+    std::fclose(f);
+    return out;
+}
+bool pin_to_cpu(int cpu) {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    CPU_SET(cpu, &set);
+    return pthread_setaffinity_np(pthread_self(), sizeof(set), &set) == 0;
+}
+// A CPU that shares the last-level cache with `me` but is another physical core, and that this thread may run on.
+int partner_cpu(int me, const cpu_set_t &allowed) {
+    const std::string base = "/sys/devices/system/cpu/cpu" + std::to_string(me);
+    const std::vector<int> l3 = read_cpu_list(base + "/cache/index3/shared_cpu_list");
+    const std::vector<int> sib = read_cpu_list(base + "/topology/thread_siblings_list");
+    int best = -1;
+    for (int c : l3) {
+        if (c == me || !CPU_ISSET(c, &allowed)) continue;
+        if (std::find(sib.begin(), sib.end(), c) != sib.end()) continue;
+        if (best < 0 || std::abs(c - me) < std::abs(best - me)) best = c;
+    }
+    return best;
+}
+#endif
+
+// Models on a second thread, range coder on the calling one.  Both are pinned (the caller's mask is restored) to two cores that
+// share an L3: unpinned, the scheduler tends to put them on different CCDs and the hand-off costs more than the split saves
+// (EPYC 9575F, ns per distance of a text block: one thread 22; two unpinned 38; two pinned 19, where the model thread is the slower
+// one -- so the dark model also moves its mantissa half to the coder's thread, see DarkCoderSide).
+// Returns DK_E_NODEVICE (reused as "not available") when no partner core can be pinned; the caller then codes on one thread.
+struct ThreadPair {
+    int me = -1, partner = -1;
+#if defined(__linux__)
+    cpu_set_t saved;
+    bool acquire() {
+        if (pthread_getaffinity_np(pthread_self(), sizeof(saved), &saved) != 0) return false;
+        me = sched_getcpu();
+        partner = me >= 0 ? partner_cpu(me, saved) : -1;
+        return partner >= 0 && pin_to_cpu(me);
+    }
+    void pin_partner() const { (void)pin_to_cpu(partner); }
+    void release() { (void)pthread_setaffinity_np(pthread_self(), sizeof(saved), &saved); }
+#else
+    bool acquire() { return false; }
+    void pin_partner() const {}
+    void release() {}
+#endif
+};
+void trace_pair(const ThreadPair &tp, const EventPipe &pipe) {
+    if (getenv("DK_TRACE"))
+        fprintf(stderr, "[dark_amd] entropy: coder on cpu %d, models on cpu %d; waits (pause iterations): models %llu, coder %llu\n",
+                tp.me, tp.partner, (unsigned long long)pipe.producer_spins, (unsigned long long)pipe.consumer_spins);
+}
+
 template <class M>
 int encode_two_threads(M &model, const DcStream &s, uint8_t *out, size_t cap, size_t *out_len) {
+    ThreadPair tp;
+    if (!tp.acquire()) return DK_E_NODEVICE;
     EventPipe pipe;
     int producer_rc = DK_OK;
-    std::thread producer([&] {
-        EventSink sink(pipe);
-        producer_rc = write_stream(model, s, sink);
-        if (producer_rc != DK_OK) sink.finish();  // write_stream finishes the sink itself on success
-    });
+    std::thread producer;
+    try {
+        producer = std::thread([&] {
+            tp.pin_partner();
+            EventSink sink(pipe);
+            producer_rc = write_stream(model, s, sink);
+            if (producer_rc != DK_OK) sink.finish();  // write_stream finishes the sink itself on success
+        });
+    } catch (...) { tp.release(); return DK_E_NODEVICE; }
     int rc = drain_pipe(pipe, out, cap, out_len);
     producer.join();
+    tp.release();
+    trace_pair(tp, pipe);
     return producer_rc ? producer_rc : rc;
 }
 
-bool use_two_threads(size_t m) {
+// dark model: exponent half on the second thread, mantissa half + range coder on the calling one
+int encode_two_threads(DarkModel &model, const DcStream &s, uint8_t *out, size_t cap, size_t *out_len) {
+    ThreadPair tp;
+    if (!tp.acquire()) return DK_E_NODEVICE;
+    EventPipe pipe;
+    int producer_rc = DK_OK;
+    std::thread producer;
+    try {
+        producer = std::thread([&] {
+            tp.pin_partner();
+            EventSink sink(pipe);
+            DarkExponentSide side{model};
+            producer_rc = write_stream(side, s, sink);
+            if (producer_rc != DK_OK) sink.finish();
+        });
+    } catch (...) { tp.release(); return DK_E_NODEVICE; }
+    auto mantissa = std::make_unique<DarkModel>();  // its own object: no cache line shared with the other thread's half
+    int rc;
+    {
+        PipeReader rd(pipe);
+        DarkCoderSide side{*mantissa, rd};
+        Encoder e(out, cap);
+        rc = write_stream(side, s, e);
+        *out_len = e.size();
+        rd.drain();
+    }
+    producer.join();
+    tp.release();
+    trace_pair(tp, pipe);
+    return producer_rc ? producer_rc : rc;
+}
+
+// 0 = automatic, 1 = one thread, 2 = two threads whenever a partner core exists
+int entropy_thread_mode() {
     static const int mode = [] { const char *e = getenv("DK_ENTROPY_THREADS"); return e ? atoi(e) : 0; }();
-    // Measured on the GPU box (EPYC 9575F): the out-of-order core already overlaps the model updates with the coder's dependency
-    // chain, and the cross-core hand-off costs more than the split saves (40 vs 36 ns per distance).  Opt-in only.
-    (void)m;
-    return mode >= 2;
+    return mode;
 }
 
 }  // namespace
 
-int encode_block_stream(int model_id, const DcStream &s, uint8_t *out, size_t cap, size_t *out_len) {
+static thread_local int t_last_threads = 1;
+int last_entropy_threads() { return t_last_threads; }
+
+int encode_block_stream(int model_id, const DcStream &s, uint8_t *out, size_t cap, size_t *out_len, int host_threads) {
     if (!s.init || (!s.dist && s.m) || (!s.sym && s.m) || !out || !out_len) return DK_E_ARG;
     if (model_id == DK_MODEL_RAWDC) return write_records(s, out, cap, out_len);
     if (s.n > model_max_block(model_id)) return DK_E_MODEL;
     return with_model(model_id, [&](auto &model) {
         model.reset();  // Encoder::new resets the model (src/block/dc.rs:31)
-        if (use_two_threads(s.m)) return encode_two_threads(model, s, out, cap, out_len);
+        const int mode = host_threads ? host_threads : entropy_thread_mode();
+        t_last_threads = 1;
+        if (mode == 2 || (mode == 0 && s.m >= (1u << 21))) {
+            const int rc2 = encode_two_threads(model, s, out, cap, out_len);
+            if (rc2 != DK_E_NODEVICE) { t_last_threads = 2; return rc2; }
+            model.reset();  // no partner core: fall through to the single-thread coder
+        }
         Encoder e(out, cap);
         int rc = write_stream(model, s, e);
         *out_len = e.size();

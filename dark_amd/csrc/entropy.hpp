@@ -184,34 +184,35 @@ private:
 // resulting intervals to a second thread that runs the (serial) range coder.  Same intervals in the same order -> the same
 // bytes.  EventSink has the put/put_pow2 interface of Encoder; EventPipe is the single-producer single-consumer ring.
 // ------------------------------------------------------------------------------------------------------------------
-struct CodeEvent { uint16_t from, to, total, pad; };  // total == 0: power-of-two total 1 << 12
+// The interval stream between the two threads, in 16-bit units: a binary decision under total 4096 (4 of 5 events) is ONE unit
+// 1 b 00 zzzzzzzzzzzz (b = coded bit, z = probability of zero); any other interval is three units from, to, total (< 2^15).
 class EventPipe;
 class EventSink {
 public:
     explicit EventSink(EventPipe &p);
     inline bool put(uint32_t total, uint32_t from, uint32_t to) {
-        if (!(from < to && to <= total && total < 65536u)) return fail(DK_E_INTERNAL);
-        push(CodeEvent{static_cast<uint16_t>(from), static_cast<uint16_t>(to), static_cast<uint16_t>(total), 0});
+        if (!(from < to && to <= total && total < 32768u)) return fail(DK_E_INTERNAL);
+        if (fill_ + 3 > cap_) flush();
+        cur_[fill_] = static_cast<uint16_t>(from);
+        cur_[fill_ + 1] = static_cast<uint16_t>(to);
+        cur_[fill_ + 2] = static_cast<uint16_t>(total);
+        fill_ += 3;
         return true;
     }
-    inline bool put_pow2(unsigned shift, uint32_t from, uint32_t to) {
-        if (!(shift == 12 && from < to && to <= 4096u)) return fail(DK_E_INTERNAL);
-        push(CodeEvent{static_cast<uint16_t>(from), static_cast<uint16_t>(to), 0, 0});
+    inline bool put_pow2(unsigned shift, uint32_t from, uint32_t to) { return put(1u << shift, from, to); }  // same quotient as the shift
+    inline bool put_bit12(uint32_t zero, bool one) {
+        if (fill_ + 1 > cap_) flush();
+        cur_[fill_++] = static_cast<uint16_t>(0x8000u | (one ? 0x4000u : 0u) | zero);
         return true;
     }
-    inline bool put_bit12(uint32_t zero, bool one) { return put_pow2(12, one ? zero : 0u, one ? 4096u : zero); }
     bool finish();  // flush the last batch and mark the end of the stream
     int error() const { return err_; }
     bool fail(int e) { if (!err_) err_ = e; return false; }
 
 private:
-    inline void push(const CodeEvent &ev) {
-        cur_[fill_++] = ev;
-        if (fill_ == cap_) flush();
-    }
     void flush();
     EventPipe &pipe_;
-    CodeEvent *cur_ = nullptr;
+    uint16_t *cur_ = nullptr;
     uint32_t fill_ = 0, cap_ = 0;
     int slot_ = 0;
     int err_ = 0;
@@ -305,6 +306,13 @@ public:
     void reset();
     template <class E> bool encode(uint32_t dist, uint8_t symbol, E &e);
     bool decode(uint8_t symbol, Decoder &d, uint32_t &dist);
+    // encode() = exponent then mantissa.  The two halves touch disjoint state (the exponent half: per-symbol and global log tables,
+    // the running average, the token context; the mantissa half: mantissa_[log] only), so two model objects on two threads can each
+    // run one half over the same distances and produce the decisions of encode() between them.
+    template <class E> bool encode_exponent(uint32_t dist, uint8_t symbol, E &e);
+    template <class E> bool encode_mantissa(uint32_t dist, E &e);
+    // number of binary decisions encode_exponent emits after its one table decision
+    static unsigned exponent_bits(uint32_t dist) { const unsigned log = bit_length(dist + 1); return log >= 8 ? log - 7 : 0; }
 
 private:
     struct PerSymbol { int64_t avg_dist; FreqTable<8> log_freq; BinFreq extra[32]; };
@@ -370,7 +378,9 @@ struct DcStream {          // what the GPU DC stage hands to the entropy stage
     uint32_t origin = 0;
 };
 // src/block/dc.rs:53-90: init-table RLE header, distances, origin, finish
-int encode_block_stream(int model_id, const DcStream &s, uint8_t *out, size_t cap, size_t *out_len);
+// host_threads: 0 = automatic (two threads for large blocks when a partner core sharing the L3 can be pinned), 1 = one thread
+int encode_block_stream(int model_id, const DcStream &s, uint8_t *out, size_t cap, size_t *out_len, int host_threads = 0);
+int last_entropy_threads();  // threads the calling thread's last encode_block_stream used
 // src/block/dc.rs:121-151: header, dc::decode pulling model.decode, origin.  *single = 1 when the block has a
 // one-symbol alphabet (the reference then mis-reads origin; see DESIGN.md "Reference quirks").
 int decode_block_stream(int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *bwt_out,
