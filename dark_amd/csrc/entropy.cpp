@@ -78,27 +78,32 @@ bool DarkModel::encode_exponent(uint32_t dist, uint8_t symbol, E &e) {  // dark.
 static_assert(kMaxLogCode == 8, "DarkModel::exponent_bits assumes MAX_LOG_CODE = 8");
 
 template <class E>
-bool DarkModel::encode_mantissa(uint32_t dist, E &e) {  // dark.rs:216-227
+bool DarkModel::encode_mantissa_modelled(uint32_t dist, E &e) {  // dark.rs:216-224: the first three bits below the leading one
     if (dist >= 0x7FFFFFFFu) return false;
     const uint32_t v = dist + 1;
     const unsigned log = bit_length(v);
     BinFreq *mc = mantissa_[log];
-    // mantissa below the leading one, MSB first: three adaptive bits, the rest through the never-updated 4th model
     const unsigned modelled = log > kMaxBitContext ? kMaxBitContext : log - 1;
     for (unsigned i = 1; i <= modelled; ++i) {
         const bool bit = (v >> (log - i - 1)) & 1u;
         if (!encode_bit_p(e, mc[i - 1].zero, bit)) return false;
         mc[i - 1].learn<8>(bit);
     }
-    const uint32_t flat = mc[kMaxBitContext].zero;
-    for (unsigned i = kMaxBitContext + 1; i < log; ++i)
-        if (!encode_bit_p(e, flat, (v >> (log - i - 1)) & 1u)) return false;
     return true;
 }
+template <class E>
+bool DarkModel::encode_mantissa_flat(uint32_t dist, E &e) {  // dark.rs:225-227: the rest through the never-updated 4th model
+    const uint32_t v = dist + 1;
+    const unsigned log = bit_length(v);
+    for (unsigned i = kMaxBitContext + 1; i < log; ++i)
+        if (!encode_bit_p(e, kModelThreshold >> 1, (v >> (log - i - 1)) & 1u)) return false;
+    return true;
+}
+static_assert(kMaxBitContext == 3, "DarkModel::modelled_mantissa_bits assumes MAX_BIT_CONTEXT = 3");
 
 template <class E>
 bool DarkModel::encode(uint32_t dist, uint8_t symbol, E &e) {  // dark.rs:180-232
-    return encode_exponent(dist, symbol, e) && encode_mantissa(dist, e);
+    return encode_exponent(dist, symbol, e) && encode_mantissa_modelled(dist, e) && encode_mantissa_flat(dist, e);
 }
 
 bool DarkModel::decode(uint8_t symbol, Decoder &d, uint32_t &dist) {  // dark.rs:234-287
@@ -642,23 +647,26 @@ private:
     bool last_ = false;
 };
 
-// The two halves of the dark model as write_stream sees them (see DarkModel::encode_exponent).
-struct DarkExponentSide {  // second thread: exponent decisions into the pipe
+// The dark model as the two threads see it: every decision that needs model state comes from the second thread through the pipe;
+// the stateless tail of the mantissa (probability 1/2 under total 4096, about a third of all decisions of a text block) is produced
+// by the coding thread itself from the distance, which takes that traffic off the pipe and evens out the two sides.
+struct DarkModelSide {  // second thread
     DarkModel &m;
-    bool encode(uint32_t dist, uint8_t symbol, EventSink &e) { return m.encode_exponent(dist, symbol, e); }
+    bool encode(uint32_t dist, uint8_t symbol, EventSink &e) {
+        return m.encode_exponent(dist, symbol, e) && m.encode_mantissa_modelled(dist, e);
+    }
 };
-struct DarkCoderSide {  // calling thread: codes the piped exponent decisions, then models and codes the mantissa itself
-    DarkModel &m;
+struct DarkCoderSide {  // calling thread
     PipeReader &rd;
     bool encode(uint32_t dist, uint8_t, Encoder &e) {
         if (dist >= 0x7FFFFFFFu) return false;
         uint32_t from, to, total;
         if (!rd.table(from, to, total) || !e.put(total, from, to)) return false;
-        for (unsigned k = DarkModel::exponent_bits(dist); k; --k) {
+        for (unsigned k = DarkModel::exponent_bits(dist) + DarkModel::modelled_mantissa_bits(dist); k; --k) {
             uint32_t zero; bool one;
             if (!rd.bit(zero, one) || !e.put_bit12(zero, one)) return false;
         }
-        return m.encode_mantissa(dist, e);
+        return DarkModel::encode_mantissa_flat(dist, e);
     }
 };
 
@@ -683,43 +691,40 @@ std::vector<int> read_cpu_list(const std::string &path) {
     std::fclose(f);
     return out;
 }
-bool pin_to_cpu(int cpu) {
-    cpu_set_t set;
-    CPU_ZERO(&set);
-    CPU_SET(cpu, &set);
-    return pthread_setaffinity_np(pthread_self(), sizeof(set), &set) == 0;
-}
-// A CPU that shares the last-level cache with `me` but is another physical core, and that this thread may run on.
-int partner_cpu(int me, const cpu_set_t &allowed) {
+// The CPUs that share the last-level cache with `me` and that this thread may run on; empty unless they span at least two
+// physical cores (a pair of SMT siblings would share one core's execution units: no gain).
+bool l3_group(int me, const cpu_set_t &allowed, cpu_set_t *group) {
     const std::string base = "/sys/devices/system/cpu/cpu" + std::to_string(me);
     const std::vector<int> l3 = read_cpu_list(base + "/cache/index3/shared_cpu_list");
     const std::vector<int> sib = read_cpu_list(base + "/topology/thread_siblings_list");
-    int best = -1;
+    CPU_ZERO(group);
+    bool other_core = false;
     for (int c : l3) {
-        if (c == me || !CPU_ISSET(c, &allowed)) continue;
-        if (std::find(sib.begin(), sib.end(), c) != sib.end()) continue;
-        if (best < 0 || std::abs(c - me) < std::abs(best - me)) best = c;
+        if (c < 0 || c >= CPU_SETSIZE || !CPU_ISSET(c, &allowed)) continue;
+        CPU_SET(c, group);
+        if (c != me && std::find(sib.begin(), sib.end(), c) == sib.end()) other_core = true;
     }
-    return best;
+    return other_core && CPU_ISSET(me, group);
 }
 #endif
 
-// Models on a second thread, range coder on the calling one.  Both are pinned (the caller's mask is restored) to two cores that
-// share an L3: unpinned, the scheduler tends to put them on different CCDs and the hand-off costs more than the split saves
+// Models on a second thread, range coder on the calling one.  Both are confined (the caller's mask is restored) to the cores that
+// share the caller's L3 -- the whole group rather than two fixed cores, so that the scheduler can still step around a core another
+// process is using: unconfined, the two threads tend to land on different CCDs and the hand-off costs more than the split saves
 // (EPYC 9575F, ns per distance of a text block: one thread 22; two unpinned 38; two pinned 19, where the model thread is the slower
 // one -- so the dark model also moves its mantissa half to the coder's thread, see DarkCoderSide).
 // Returns DK_E_NODEVICE (reused as "not available") when no partner core can be pinned; the caller then codes on one thread.
 struct ThreadPair {
-    int me = -1, partner = -1;
+    int me = -1;
 #if defined(__linux__)
-    cpu_set_t saved;
+    cpu_set_t saved, group;
     bool acquire() {
         if (pthread_getaffinity_np(pthread_self(), sizeof(saved), &saved) != 0) return false;
         me = sched_getcpu();
-        partner = me >= 0 ? partner_cpu(me, saved) : -1;
-        return partner >= 0 && pin_to_cpu(me);
+        if (me < 0 || me >= CPU_SETSIZE || !l3_group(me, saved, &group)) return false;
+        return pthread_setaffinity_np(pthread_self(), sizeof(group), &group) == 0;
     }
-    void pin_partner() const { (void)pin_to_cpu(partner); }
+    void pin_partner() const { (void)pthread_setaffinity_np(pthread_self(), sizeof(group), &group); }
     void release() { (void)pthread_setaffinity_np(pthread_self(), sizeof(saved), &saved); }
 #else
     bool acquire() { return false; }
@@ -729,8 +734,8 @@ struct ThreadPair {
 };
 void trace_pair(const ThreadPair &tp, const EventPipe &pipe) {
     if (getenv("DK_TRACE"))
-        fprintf(stderr, "[dark_amd] entropy: coder on cpu %d, models on cpu %d; waits (pause iterations): models %llu, coder %llu\n",
-                tp.me, tp.partner, (unsigned long long)pipe.producer_spins, (unsigned long long)pipe.consumer_spins);
+        fprintf(stderr, "[dark_amd] entropy: two threads inside the L3 group of cpu %d; waits (pause iterations): models %llu, coder %llu\n",
+                tp.me, (unsigned long long)pipe.producer_spins, (unsigned long long)pipe.consumer_spins);
 }
 
 template <class M>
@@ -755,7 +760,7 @@ int encode_two_threads(M &model, const DcStream &s, uint8_t *out, size_t cap, si
     return producer_rc ? producer_rc : rc;
 }
 
-// dark model: exponent half on the second thread, mantissa half + range coder on the calling one
+// dark model: all stateful modelling on the second thread; stateless mantissa tail + range coder on the calling one
 int encode_two_threads(DarkModel &model, const DcStream &s, uint8_t *out, size_t cap, size_t *out_len) {
     ThreadPair tp;
     if (!tp.acquire()) return DK_E_NODEVICE;
@@ -766,16 +771,15 @@ int encode_two_threads(DarkModel &model, const DcStream &s, uint8_t *out, size_t
         producer = std::thread([&] {
             tp.pin_partner();
             EventSink sink(pipe);
-            DarkExponentSide side{model};
+            DarkModelSide side{model};
             producer_rc = write_stream(side, s, sink);
             if (producer_rc != DK_OK) sink.finish();
         });
     } catch (...) { tp.release(); return DK_E_NODEVICE; }
-    auto mantissa = std::make_unique<DarkModel>();  // its own object: no cache line shared with the other thread's half
     int rc;
     {
         PipeReader rd(pipe);
-        DarkCoderSide side{*mantissa, rd};
+        DarkCoderSide side{rd};
         Encoder e(out, cap);
         rc = write_stream(side, s, e);
         *out_len = e.size();

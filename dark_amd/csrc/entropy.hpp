@@ -306,13 +306,14 @@ public:
     void reset();
     template <class E> bool encode(uint32_t dist, uint8_t symbol, E &e);
     bool decode(uint8_t symbol, Decoder &d, uint32_t &dist);
-    // encode() = exponent then mantissa.  The two halves touch disjoint state (the exponent half: per-symbol and global log tables,
-    // the running average, the token context; the mantissa half: mantissa_[log] only), so two model objects on two threads can each
-    // run one half over the same distances and produce the decisions of encode() between them.
+    // encode() = exponent, modelled mantissa bits, flat mantissa bits.  The last part reads no model state at all, so a second
+    // thread that knows the distance can produce those decisions by itself (two-thread encode, entropy.cpp).
     template <class E> bool encode_exponent(uint32_t dist, uint8_t symbol, E &e);
-    template <class E> bool encode_mantissa(uint32_t dist, E &e);
+    template <class E> bool encode_mantissa_modelled(uint32_t dist, E &e);
+    template <class E> static bool encode_mantissa_flat(uint32_t dist, E &e);  // stateless
     // number of binary decisions encode_exponent emits after its one table decision
     static unsigned exponent_bits(uint32_t dist) { const unsigned log = bit_length(dist + 1); return log >= 8 ? log - 7 : 0; }
+    static unsigned modelled_mantissa_bits(uint32_t dist) { const unsigned log = bit_length(dist + 1); return log > 3 ? 3 : log - 1; }
 
 private:
     struct PerSymbol { int64_t avg_dist; FreqTable<8> log_freq; BinFreq extra[32]; };
