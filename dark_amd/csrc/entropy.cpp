@@ -403,10 +403,20 @@ int write_records(const DcStream &s, uint8_t *out, size_t cap, size_t *out_len) 
 
 // compress::bwt::dc::decode: rebuilds the BWT from first positions + distances while keeping the symbols ordered by
 // their next known position (the decoder's view of the MTF list).  `next_dist(symbol, &d)` supplies distances.
+inline void fill_run(uint8_t *out, size_t n, size_t i, size_t stop, uint8_t sym) {
+    if (stop - i <= 16 && i + 16 <= n) {  // BWT runs are short: one unconditional 16-byte splat beats a memset call
+        uint8_t splat[16];
+        std::memset(splat, sym, 16);
+        std::memcpy(out + i, splat, 16);
+    } else {
+        std::memset(out + i, sym, stop - i);
+    }
+}
+
 template <class F>
 int dc_rebuild(uint32_t const init[256], uint8_t *out, size_t n, F &&next_dist, int *single) {
     uint64_t next[256];
-    uint8_t order[256];
+    uint8_t order[256 + 16];
     size_t alpha = 0;
     for (int s = 0; s < 256; ++s) {
         next[s] = init[s];
@@ -421,30 +431,28 @@ int dc_rebuild(uint32_t const init[256], uint8_t *out, size_t n, F &&next_dist, 
         std::memset(out, alpha ? order[0] : 0, n);
         return DK_OK;
     }
+    // the positions are kept in list order beside the symbols (no next[order[r]] double load inside the sinking loop)
+    uint64_t pos[256 + 1];
+    for (size_t j = 0; j < alpha; ++j) pos[j] = next[order[j]];
+    pos[alpha] = ~0ull;  // sentinel: ends the sinking loop
     size_t i = 0;
     while (i < n) {
         const uint8_t sym = order[0];
-        const uint64_t stop = next[order[1]];
+        const uint64_t stop = pos[1];
         if (stop > n || stop < i) return DK_E_STREAM;
-        if (stop - i <= 16 && i + 16 <= n) {  // BWT runs are short: one unconditional 16-byte splat beats a memset call
-            uint8_t splat[16];
-            std::memset(splat, sym, 16);
-            std::memcpy(out + i, splat, 16);
-        } else {
-            std::memset(out + i, sym, stop - i);
-        }
+        fill_run(out, n, i, stop, sym);
         i = stop;
         uint32_t d;
         if (int rc = next_dist(sym, &d)) return rc;
         const uint64_t future = stop + d;
         if (future > n) return DK_E_STREAM;
         size_t r = 1;
-        while (r < alpha && future + r > next[order[r]]) { order[r - 1] = order[r]; ++r; }
+        while (future + r > pos[r]) { order[r - 1] = order[r]; pos[r - 1] = pos[r]; ++r; }
         order[r - 1] = sym;
-        next[sym] = future + r - 1;
+        pos[r - 1] = future + r - 1;
     }
-    for (int s = 0; s < 256; ++s)
-        if (next[s] < n || next[s] >= n + alpha) return DK_E_STREAM;
+    for (size_t j = 0; j < alpha; ++j)
+        if (pos[j] < n || pos[j] >= n + alpha) return DK_E_STREAM;
     return DK_OK;
 }
 

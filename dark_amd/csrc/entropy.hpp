@@ -154,8 +154,9 @@ public:
 private:
     inline void feed() {
         const unsigned k = static_cast<unsigned>(pending_);
-        if (__builtin_expect(k == 0, 0)) return;
-        if (__builtin_expect(pos_ + 4 <= len_, 1)) {  // take k (1..4) bytes out of one unconditional 4-byte big-endian load
+        // k == 0 (no byte left the coder in the last step) is frequent and irregular: it goes through the same arithmetic
+        // (shift by 32 - 0) rather than through a branch the predictor cannot learn
+        if (__builtin_expect(pos_ + 4 <= len_, 1)) {  // take k (0..4) bytes out of one unconditional 4-byte big-endian load
             uint32_t be;
             std::memcpy(&be, in_ + pos_, 4);
             const uint64_t w = __builtin_bswap32(be);
