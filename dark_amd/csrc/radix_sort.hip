@@ -32,7 +32,7 @@ __device__ __forceinline__ uint32_t digit_of(uint64_t k, int shift) { return sta
 template <bool PAIRS>
 __device__ __forceinline__ uint64_t load_key(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ hi,
                                              const uint32_t *__restrict__ lo, size_t i) {
-    if (PAIRS) return (static_cast<uint64_t>(hi[i]) << 32) | lo[i];
+    if (PAIRS) return (static_cast<uint64_t>(hi[i]) << 32) | (lo ? lo[i] : static_cast<uint32_t>(i));  // lo == nullptr: lo[i] = i
     return keys[i];
 }
 
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(RS_BLOCK) void k_bucket_store(const uint64_t *__res
     }
 }
 
-// dst[idx[i]] = val[i], i < count; idx values are distinct and < limit.  `scratch` holds count u64.
+// dst[idx[i]] = val[i] (val == nullptr: = i), i < count; idx values are distinct and < limit.  `scratch` holds count u64.
 int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, size_t count, size_t limit, uint64_t *scratch,
                          uint32_t *dst) {
     if (count == 0) return DK_OK;

@@ -10,7 +10,9 @@
 //   5. while active:     key = (group id, rank2) with rank2 = rank[i+h]+h, or n-1-i for i+h >= n (shorter is smaller);
 //                        sort_pairs on exactly the bits in use; rerank; h *= 2
 // Only members of unresolved groups are ever sorted again (Larsson-Sadakane style filtering).
+#include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "context.hpp"
 #include "device_util.hpp"
@@ -98,6 +100,66 @@ __global__ __launch_bounds__(PK_BLOCK) void k_pack_keys(const uint8_t *__restric
 __global__ __launch_bounds__(256) void k_sa_descending(uint32_t *__restrict__ sa, size_t n) {
     const size_t j = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (j < n) sa[j] = static_cast<uint32_t>(n - 1 - j);
+}
+
+// codes of T[p .. p+count) packed big-endian, zero padded past the end of the text (count * bits <= 64)
+__device__ __forceinline__ uint64_t text_key(const uint8_t *__restrict__ t, size_t n, const uint8_t *__restrict__ code, size_t p, int bits,
+                                             int count) {
+    uint64_t key = 0;
+    for (int j = 0; j < count; ++j) {
+        const size_t q = p + j;
+        key = (key << bits) | (q < n ? code[t[q]] : 0u);
+    }
+    return key;
+}
+
+// ---- how many leading symbols does the initial sort need? -------------------------------------------------------------
+// m suffixes at distinct, evenly spread (jittered) positions; for each candidate prefix length the prefixes go into one hash table
+// and equal ones are counted.  m is about 10 sqrt(n), so a sample without any equal pair says that (with high probability) fewer
+// than a few percent of ALL suffixes share their prefix of that length with another suffix: sorting by that prefix alone leaves a
+// small active list, which one text-extension round finishes.  Text-like inputs show thousands of equal pairs at every length
+// and keep the full key.
+constexpr int PP_MAX_CAND = 4;
+struct ProbeCands { int count; int sym[PP_MAX_CAND]; };
+constexpr uint64_t PP_EMPTY = ~0ull;
+
+__global__ __launch_bounds__(256) void k_prefix_probe(const uint8_t *__restrict__ t, size_t n, const uint8_t *__restrict__ code, int bits,
+                                                      int spk, uint32_t m, uint32_t span, ProbeCands cands, uint64_t *__restrict__ table,
+                                                      uint32_t table_mask, uint32_t *__restrict__ dups) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    uint32_t hsh = i * 2654435761u;
+    hsh ^= hsh >> 15;
+    const size_t pos = static_cast<size_t>(i) * span + (hsh % span);
+    if (pos >= n) return;
+    const uint64_t key = text_key(t, n, code, pos, bits, spk);
+    for (int c = 0; c < cands.count; ++c) {
+        const uint64_t tagged = ((key >> (bits * (spk - cands.sym[c]))) << 2) | static_cast<uint64_t>(c);  // at most 58 bits
+        uint64_t x = tagged * 0x9E3779B97F4A7C15ull;
+        uint32_t slot = static_cast<uint32_t>(x >> 32) & table_mask;
+        for (uint32_t tries = 0; tries <= table_mask; ++tries) {
+            const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long *>(table + slot), static_cast<unsigned long long>(PP_EMPTY),
+                                           static_cast<unsigned long long>(tagged));
+            if (old == PP_EMPTY) break;
+            if (old == tagged) { atomicAdd(&dups[c], 1u); break; }
+            slot = (slot + 1) & table_mask;
+        }
+    }
+}
+
+// ---- rank array for the doubling rounds when the initial sort did not produce it (short-prefix path) ------------------------------
+// Every suffix that is final sits in SA; put the active ones at their (provisional) places too, store rank[SA[p]] = p for all p
+// with the bucketed scatter, then give the active ones the position of their group's head.
+__global__ __launch_bounds__(256) void k_place_active(const uint32_t *__restrict__ act_idx, const uint32_t *__restrict__ act_pos, size_t count,
+                                                      uint32_t *__restrict__ sa) {
+    const size_t a = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (a < count) sa[act_pos[a]] = act_idx[a];
+}
+__global__ __launch_bounds__(256) void k_rank_active(const uint32_t *__restrict__ act_idx, const uint32_t *__restrict__ act_pos,
+                                                     const uint32_t *__restrict__ act_gid, const uint32_t *__restrict__ gstart, size_t count,
+                                                     uint32_t *__restrict__ rank) {
+    const size_t a = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (a < count) rank[act_idx[a]] = act_pos[gstart[act_gid[a]]];
 }
 
 // ---- rerank: three kernels sharing the per-slot flag logic ------------------------------------------------------
@@ -394,21 +456,32 @@ __device__ __forceinline__ uint32_t rank2_of(const uint32_t *__restrict__ rank, 
     return p < n ? rank[p] + h : static_cast<uint32_t>(static_cast<uint64_t>(n) + h - 1 - p);
 }
 
+// TEXT = true (text-extension round of the short-prefix path): the secondary key is not a rank but the next `tsym` symbols of the
+// text after the h already sorted ones, packed like the initial keys (64-bit secondary keys in LDS).
+struct TextSource { const uint8_t *text; const uint8_t *code; int bits; int tsym; };
+
+template <bool TEXT>
 __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__restrict__ act_idx, const uint32_t *__restrict__ act_gid,
                                                           const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ bigstart,
                                                           const uint32_t *__restrict__ rank, uint32_t n, uint32_t h, int kbits,
                                                           size_t count, uint64_t *__restrict__ key_out, uint32_t *__restrict__ idx_out,
-                                                          uint64_t *__restrict__ bkeys, uint32_t *__restrict__ bidx) {
-    __shared__ uint32_t s_r2[LS_TILE + 2 * LS_MAX];
+                                                          uint64_t *__restrict__ bkeys, uint32_t *__restrict__ bidx, TextSource ts) {
+    using R2 = typename std::conditional<TEXT, uint64_t, uint32_t>::type;
+    __shared__ R2 s_r2[LS_TILE + 2 * LS_MAX];
+    auto second = [&](uint32_t suffix) -> R2 {
+        if (TEXT) return static_cast<R2>(text_key(ts.text, n, ts.code, static_cast<size_t>(suffix) + h, ts.bits, ts.tsym));
+        return static_cast<R2>(rank2_of(rank, suffix, n, h));
+    };
     const int tid = threadIdx.x;
     const size_t b0 = static_cast<size_t>(blockIdx.x) * LS_TILE;
-    uint32_t my_idx[LS_IPT], my_r2[LS_IPT];
+    uint32_t my_idx[LS_IPT];
+    R2 my_r2[LS_IPT];
 #pragma unroll
     for (int k = 0; k < LS_IPT; ++k) {
         const size_t a = b0 + static_cast<size_t>(k) * LS_BLOCK + tid;
         if (a < count) {
             my_idx[k] = act_idx[a];
-            my_r2[k] = rank2_of(rank, my_idx[k], n, h);
+            my_r2[k] = second(my_idx[k]);
             s_r2[LS_MAX + k * LS_BLOCK + tid] = my_r2[k];
         }
     }
@@ -418,7 +491,7 @@ __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__rest
         // slot index = b0 - LS_MAX + off; guard both ends of the list
         if (b0 + off >= static_cast<size_t>(LS_MAX) && b0 + off - LS_MAX < count) {
             const size_t a = b0 + off - LS_MAX;
-            s_r2[off] = rank2_of(rank, act_idx[a], n, h);
+            s_r2[off] = second(act_idx[a]);
         }
     }
     __syncthreads();
@@ -430,12 +503,12 @@ __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__rest
         const uint32_t gs = gstart[g], ge = gstart[g + 1];
         const uint64_t key = (static_cast<uint64_t>(g) << kbits) | my_r2[k];
         if (ge - gs <= static_cast<uint32_t>(LS_MAX)) {
-            const uint32_t mine = my_r2[k];
+            const R2 mine = my_r2[k];
             // LDS index of slot b is b - (b0 - LS_MAX) = b + LS_MAX - b0 (never negative: gs >= a - LS_MAX + 1)
             const uint32_t base = static_cast<uint32_t>(LS_MAX) - static_cast<uint32_t>(b0);  // mod 2^32 arithmetic
             uint32_t before = 0;
             for (uint32_t b = gs; b < ge; ++b) {
-                const uint32_t v = s_r2[b + base];
+                const R2 v = s_r2[b + base];
                 before += (v < mine) || (v == mine && b < static_cast<uint32_t>(a));
             }
             key_out[gs + before] = key;
@@ -541,19 +614,64 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
         !gstart || !bigstart)
         return DK_E_NOMEM;
     DK_HIP(ctx, hipMemcpyAsync(d_code, code, 256, hipMemcpyHostToDevice, st));
+    static const bool trace = getenv("DK_TRACE") != nullptr;
 
-    // 2.-3. initial keys and sort
+    // 2. how long a prefix must the initial sort cover?  DK_PREFIX: 0 = always the full key, 1 = ask the sample (default),
+    //    2 = always the shortest candidate (test hook: every input then takes the short-prefix path)
+    static const int prefix_mode = [] { const char *e = getenv("DK_PREFIX"); return e ? atoi(e) : 1; }();
+    int spk_sort = spk;
+    if (prefix_mode != 0 && (n >= (1u << 22) || prefix_mode == 2)) {
+        ProbeCands cands{0, {0, 0, 0, 0}};
+        for (int passes = 4; passes <= 7 && cands.count < PP_MAX_CAND; ++passes) {
+            const int k = (8 * passes) / bits;
+            if (k >= 1 && k < spk && (cands.count == 0 || cands.sym[cands.count - 1] != k)) cands.sym[cands.count++] = k;
+        }
+        if (cands.count > 0 && prefix_mode == 2) {
+            spk_sort = cands.sym[0];
+        } else if (cands.count > 0) {
+            const uint32_t m = static_cast<uint32_t>(std::min<double>(n / 2.0, 10.0 * std::sqrt(static_cast<double>(n))));
+            const uint32_t span = static_cast<uint32_t>(n / m);
+            uint32_t table_size = 1;
+            while (table_size < 2u * cands.count * m) table_size <<= 1;
+            uint64_t *table = keys_3;  // free until the first big-group sort
+            uint32_t *d_dups = ctx->d_mail + 300;
+            DK_HIP(ctx, hipMemsetAsync(table, 0xFF, static_cast<size_t>(table_size) * sizeof(uint64_t), st));
+            DK_HIP(ctx, hipMemsetAsync(d_dups, 0, PP_MAX_CAND * sizeof(uint32_t), st));
+            {
+                LaunchScope ls(ctx, K_MISC, 16.0 * m);
+                k_prefix_probe<<<dim3(div_up(m, 256)), dim3(256), 0, st>>>(d_text, n, d_code, bits, spk, m, span, cands, table, table_size - 1,
+                                                                          d_dups);
+            }
+            DK_HIP(ctx, hipGetLastError());
+            DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 300, d_dups, PP_MAX_CAND * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            DK_HIP(ctx, hipStreamSynchronize(st));
+            for (int c = 0; c < cands.count; ++c)
+                if (ctx->h_mail[300 + c] == 0) { spk_sort = cands.sym[c]; break; }
+            if (trace)
+                fprintf(stderr, "[dk] prefix probe: %u samples, equal pairs at %d/%d/%d/%d symbols: %u %u %u %u -> sort %d of %d symbols\n", m,
+                        cands.sym[0], cands.sym[1], cands.sym[2], cands.sym[3], ctx->h_mail[300], ctx->h_mail[301], ctx->h_mail[302],
+                        ctx->h_mail[303], spk_sort, spk);
+        }
+    }
+    const bool short_prefix = spk_sort < spk;
+
+    // 3. initial keys and sort
     {
         LaunchScope ls(ctx, K_PACK_KEYS, 1.0 * n + 12.0 * n);
-        k_pack_keys<<<dim3(div_up(n, PK_TILE)), dim3(PK_BLOCK), 0, st>>>(d_text, n, d_code, bits, spk, keys, vals);
+        k_pack_keys<<<dim3(div_up(n, PK_TILE)), dim3(PK_BLOCK), 0, st>>>(d_text, n, d_code, bits, spk_sort, keys, vals);
     }
     DK_HIP(ctx, hipGetLastError());
-    DK_TRY(sort_pairs(ctx, keys, keys_alt, vals, vals_alt, n, 0, bits * spk));
+    DK_TRY(sort_pairs(ctx, keys, keys_alt, vals, vals_alt, n, 0, bits * spk_sort));
 
     // 4. first rerank (slots are SA positions)
     size_t active = 0, groups = 0, nbig = 0;
+    bool have_ranks = true;
     static const bool bucketed = [] { const char *e = getenv("DK_BUCKETED"); return !(e && e[0] == '0'); }();
-    if (bucketed && n >= (1u << 22)) {
+    if (short_prefix) {
+        // few suffixes are expected to survive and they are finished from the text: no rank array unless that fails (step 5b)
+        DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, nullptr, d_sa, vals_alt, pos, gid, gstart));
+        have_ranks = false;
+    } else if (bucketed && n >= (1u << 22)) {
         // rank[suffix] = head position for all n suffixes: too random for plain stores (every 4-byte store is a 64-byte line
         // at the HBM) -> the rerank only lists the head positions, the bucketed scatter stores them XCD-locally
         bool need_ranks = true;
@@ -565,22 +683,25 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     DK_TRY(classify_and_read(ctx, n / 2, gstart, bigstart, &active, &groups, &nbig));
     std::swap(vals, vals_alt);  // vals = suffix indices of the active list
 
-    // 5. doubling rounds
-    uint64_t h = static_cast<uint64_t>(spk);
-    static const bool trace = getenv("DK_TRACE") != nullptr;
+    uint64_t h = static_cast<uint64_t>(spk_sort);
     if (trace)
-        fprintf(stderr, "[dk] n=%zu sigma=%u bits=%d spk=%d: after init sort active=%zu groups=%zu big=%zu\n", n, sigma, bits, spk,
+        fprintf(stderr, "[dk] n=%zu sigma=%u bits=%d spk=%d: after init sort active=%zu groups=%zu big=%zu\n", n, sigma, bits, spk_sort,
                 active, groups, nbig);
-    while (active > 0) {
-        if (ctx->stats.rounds > 40) return ctx->fail(DK_E_INTERNAL, "suffix_array: no convergence after 40 rounds");
-        const uint32_t h_eff = static_cast<uint32_t>(std::min<uint64_t>(h, n));
-        const int kbits = static_cast<int>(ceil_log2_u64(static_cast<uint64_t>(n) + h_eff));
+
+    // one round: secondary keys (ranks h further on, or the next tsym symbols of the text) -> every group sorted inside its own
+    // slot range (small groups in LDS, big ones through the global sort) -> rerank
+    auto run_round = [&](int kbits, int tsym) -> int {
         const int gbits = static_cast<int>(ceil_log2_u64(groups));
-        // small groups: sorted in LDS; big groups: copied to (keys_alt, vals_3) for the global sort
+        const uint32_t h_eff = static_cast<uint32_t>(std::min<uint64_t>(h, n));
+        const TextSource ts{d_text, d_code, bits, tsym};
         {
             LaunchScope ls(ctx, K_BUILD_KEYS, 8.0 * active + 4.0 * active + 12.0 * active);
-            k_round_local<<<dim3(div_up(active, LS_TILE)), dim3(LS_BLOCK), 0, st>>>(vals, gid, gstart, bigstart, rank, static_cast<uint32_t>(n),
-                                                                                    h_eff, kbits, active, keys, vals_alt, keys_alt, vals_3);
+            if (tsym > 0)
+                k_round_local<true><<<dim3(div_up(active, LS_TILE)), dim3(LS_BLOCK), 0, st>>>(
+                    vals, gid, gstart, bigstart, rank, static_cast<uint32_t>(n), h_eff, kbits, active, keys, vals_alt, keys_alt, vals_3, ts);
+            else
+                k_round_local<false><<<dim3(div_up(active, LS_TILE)), dim3(LS_BLOCK), 0, st>>>(
+                    vals, gid, gstart, bigstart, rank, static_cast<uint32_t>(n), h_eff, kbits, active, keys, vals_alt, keys_alt, vals_3, ts);
         }
         DK_HIP(ctx, hipGetLastError());
         if (nbig > 0) {
@@ -593,19 +714,50 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
             }
             DK_HIP(ctx, hipGetLastError());
         }
-        // keys / vals_alt now hold every group sorted by rank2 in its own slot range
+        // keys / vals_alt now hold every group sorted by its secondary key in its own slot range
         size_t next_active = 0, next_groups = 0, next_big = 0;
-        DK_TRY(rerank(ctx, keys, vals_alt, pos, active, kbits, rank, d_sa, vals, pos_alt, gid_alt, gstart));
+        DK_TRY(rerank(ctx, keys, vals_alt, pos, active, kbits, have_ranks ? rank : nullptr, d_sa, vals, pos_alt, gid_alt, gstart));
         DK_TRY(classify_and_read(ctx, active / 2, gstart, bigstart, &next_active, &next_groups, &next_big, nbig == 0));
         std::swap(pos, pos_alt);
         std::swap(gid, gid_alt);
         if (trace)
-            fprintf(stderr, "[dk] round %u h=%llu slots=%zu big=%zu bits=%d -> active=%zu groups=%zu big=%zu\n", ctx->stats.rounds,
-                    (unsigned long long)h, active, nbig, kbits + gbits, next_active, next_groups, next_big);
+            fprintf(stderr, "[dk] round %u h=%llu%s slots=%zu big=%zu bits=%d -> active=%zu groups=%zu big=%zu\n", ctx->stats.rounds,
+                    (unsigned long long)h, tsym > 0 ? " (text)" : "", active, nbig, kbits + gbits, next_active, next_groups, next_big);
         active = next_active;
         groups = next_groups;
         nbig = next_big;
         ctx->stats.rounds += 1;
+        return DK_OK;
+    };
+
+    // 5a. short-prefix path: extend the survivors' keys from the text (as many further symbols as fit beside the group id)
+    for (int t = 0; short_prefix && active > 0 && t < 2; ++t) {
+        const int gbits = static_cast<int>(ceil_log2_u64(groups));
+        const int tsym = std::min(spk, (63 - gbits) / bits);
+        if (tsym < 1) break;
+        DK_TRY(run_round(tsym * bits, tsym));
+        h += static_cast<uint64_t>(tsym);
+    }
+    // 5b. survivors beyond that (long repeats): build the rank array the doubling rounds need
+    if (active > 0 && !have_ranks) {
+        {
+            LaunchScope ls(ctx, K_MISC, 12.0 * active);
+            k_place_active<<<dim3(div_up(active, 256)), dim3(256), 0, st>>>(vals, pos, active, d_sa);
+        }
+        DK_TRY(scatter_u32_bucketed(ctx, d_sa, nullptr, n, n, keys_alt, rank));  // rank[SA[p]] = p
+        {
+            LaunchScope ls(ctx, K_MISC, 16.0 * active);
+            k_rank_active<<<dim3(div_up(active, 256)), dim3(256), 0, st>>>(vals, pos, gid, gstart, active, rank);
+        }
+        DK_HIP(ctx, hipGetLastError());
+        have_ranks = true;
+    }
+
+    // 5c. doubling rounds
+    while (active > 0) {
+        if (ctx->stats.rounds > 44) return ctx->fail(DK_E_INTERNAL, "suffix_array: no convergence after 44 rounds");
+        const uint32_t h_eff = static_cast<uint32_t>(std::min<uint64_t>(h, n));
+        DK_TRY(run_round(static_cast<int>(ceil_log2_u64(static_cast<uint64_t>(n) + h_eff)), 0));
         h *= 2;
     }
     ctx->ws_release(mark);

@@ -42,6 +42,44 @@ print("ok")
 """
 
 
+# the short-prefix path of the suffix sort (DK_PREFIX: 0 = never, 1 = ask the sample, 2 = always): initial sort on a few leading
+# symbols, survivors finished from the text, rank array built late only when long repeats remain
+PREFIX_SNIPPET = r"""
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+import dark_amd
+from dark_amd import datagen
+from oracle import orc
+rng = np.random.default_rng(11)
+def planted(base, seg_len, copies):
+    t = base.copy()
+    seg = t[1000:1000 + seg_len].copy()
+    for c in range(copies):
+        o = int(rng.integers(0, len(t) - seg_len))
+        t[o:o + seg_len] = seg
+    return t
+cases = [
+    ("random bytes 5M", rng.integers(0, 256, size=5_000_000, dtype=np.uint8)),
+    ("random bytes + 3 copies of 50 KB", planted(rng.integers(0, 256, size=5_000_000, dtype=np.uint8), 50_000, 3)),
+    ("acgt 5M", datagen.acgt(5_000_000, 4)),
+    ("acgt + repeats", planted(datagen.acgt(4_500_000, 5), 20_000, 4)),
+    ("zero-heavy", np.where(rng.random(4_300_000) < 0.9, 0, rng.integers(0, 7, size=4_300_000)).astype(np.uint8)),
+    ("ends in zeros", np.concatenate([rng.integers(0, 256, size=4_200_000, dtype=np.uint8), np.zeros(3000, np.uint8)])),
+]
+if os.environ.get("DK_PREFIX") == "2":
+    cases += [("text", datagen.wiki_like(3_000_000, 9)), ("ab", np.frombuffer(b"ab" * 40000, np.uint8)),
+              ("one", np.array([7], np.uint8)), ("two", np.array([1, 1], np.uint8)), ("tiny", rng.integers(0, 3, size=70, dtype=np.uint8)),
+              ("run then one", np.concatenate([np.zeros(100000, np.uint8), np.ones(1, np.uint8)])),
+              ("binary", rng.integers(0, 2, size=1_000_000, dtype=np.uint8))]
+with dark_amd.Context(6 << 20) as ctx:
+    for name, t in cases:
+        t = np.ascontiguousarray(t)
+        want = orc.sa_sais(t) if len(t) > 1 else np.zeros(1, np.uint32)
+        assert (ctx.suffix_array(t) == want).all(), name
+print("ok")
+"""
+
+
 def _run(snippet, env):
     e = dict(os.environ)
     e.update(env)
@@ -58,3 +96,9 @@ def test_two_thread_entropy_is_bit_exact():
 @pytest.mark.parametrize("env", [{"DK_SORT": "onesweep"}, {"DK_SORT": "chunked"}, {"DK_BUCKETED": "0"}, {"DK_XCD": "0"}])
 def test_gpu_variants_match_oracle(env):
     _run(GPU_SNIPPET, env)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_gpu_prefix_paths_match_oracle(mode):
+    _run(PREFIX_SNIPPET, {"DK_PREFIX": mode, "DK_TRACE": "1"})
