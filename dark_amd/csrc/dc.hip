@@ -27,6 +27,7 @@ constexpr int DC_WAVES = DC_BLOCK / 64;
 constexpr int DC_TILE = 4096;        // positions per wave
 constexpr int DC_PAD = 16;           // tile bytes start at offset 16 in LDS; byte 15 holds L[base-1]
 constexpr int DC_MAX_CHUNKS = 256;
+constexpr int DC_WIDE_B = 20;        // first occurrences per chunk above which their ranks are counted lane-parallel
 
 // Stage L[base-1 .. base+DC_TILE] of one tile into wave-private LDS: s[DC_PAD + j] = L[base + j].
 __device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ L, size_t n, size_t base, uint8_t *s, int lane) {
@@ -171,7 +172,8 @@ __device__ __forceinline__ uint32_t write_lane(uint32_t value, int sel, uint32_t
 //           first of their symbol inside that window (prevsame[q] <= w), counted by shifting prevsame one lane per step;
 //   case B  first occurrence of the symbol in this chunk: previous occurrence b from the tile table (state before the chunk),
 //           rank = #{table symbols with last position > b} + #{symbols first seen in this chunk before the lane whose table
-//           position is <= b}; a short scalar loop over these lanes (at most one per distinct symbol of the chunk).
+//           position is <= b}; a short scalar loop over these lanes (at most one per distinct symbol of the chunk), or, when
+//           there are many of them, every lane for itself over the whole table.
 // Then every run-start lane stores its own outputs, and the last lane of every symbol updates the tile table.
 __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict__ L, size_t n, size_t ntiles,
                                                        const uint32_t *__restrict__ carry_last, const uint32_t *__restrict__ carry_lrun,
@@ -247,9 +249,27 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
             }
         }
         // ---- case B: first occurrence of the symbol in this chunk; the previous one (if any) is in the table
-        {
-            const bool first_here = valid && prevsame < 0;
-            uint64_t mB = __ballot(isB);
+        const bool first_here = valid && prevsame < 0;
+        uint64_t mB = __ballot(isB);
+        if (__popcll(mB) > DC_WIDE_B) {
+            // many first occurrences (large alphabets: random bytes have ~57 per chunk): every lane counts for itself -- the 256 table
+            // positions arrive as 64 broadcast 16-byte LDS reads, then the symbols first seen earlier in this chunk
+            const uint32_t b1 = tab.x;
+            uint32_t rk = 0;
+#pragma unroll 4
+            for (int t = 0; t < 64; ++t) {
+                const uint4 e = *reinterpret_cast<const uint4 *>(pos + 4 * t);
+                rk += (e.x > b1 ? 1u : 0u) + (e.y > b1 ? 1u : 0u) + (e.z > b1 ? 1u : 0u) + (e.w > b1 ? 1u : 0u);
+            }
+            uint64_t fm = __ballot(first_here);
+            while (fm) {
+                const int bit = __builtin_ctzll(fm);
+                fm &= fm - 1;
+                const uint32_t tq = __builtin_amdgcn_readlane(tab.x, bit);
+                rk += (bit < lane && tq <= b1) ? 1u : 0u;
+            }
+            if (isB) cnt = b1 ? rk : 0u;
+        } else {
             while (mB) {
                 const int bit = __builtin_ctzll(mB);
                 mB &= mB - 1;
