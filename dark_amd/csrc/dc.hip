@@ -27,6 +27,7 @@ constexpr int DC_WAVES = DC_BLOCK / 64;
 constexpr int DC_TILE = 4096;        // positions per wave
 constexpr int DC_PAD = 16;           // tile bytes start at offset 16 in LDS; byte 15 holds L[base-1]
 constexpr int DC_MAX_CHUNKS = 256;
+constexpr int DC_FEW_A = 12;         // case-A lanes per chunk up to which each gets its own ballot instead of the shift loop
 constexpr int DC_WIDE_B = 20;        // first occurrences per chunk above which their ranks are counted lane-parallel
 
 // Stage L[base-1 .. base+DC_TILE] of one tile into wave-private LDS: s[DC_PAD + j] = L[base + j].
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[DC_WAVES][DC_PAD + DC_TILE + 16];
     __shared__ __attribute__((aligned(16))) uint32_t s_pos[DC_WAVES][256];
     __shared__ __attribute__((aligned(16))) uint2 s_pr[DC_WAVES][256];
+    __shared__ unsigned long long s_bm[DC_WAVES][DC_TILE / 64];  // wide tiles: bit j = position j of the tile is the last occurrence of its symbol
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t tile = static_cast<size_t>(blockIdx.x) * DC_WAVES + wave;
     if (tile >= ntiles) return;
@@ -191,6 +193,9 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
     uint8_t *s = s_tile[wave];
     uint32_t *pos = s_pos[wave];
     uint2 *pr = s_pr[wave];
+    unsigned long long *bm = s_bm[wave];
+    bm[lane] = 0;
+    bool wide = false;  // wave-uniform, decided at the tile's first chunk
     stage_tile(L, n, base, s, lane);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -216,6 +221,11 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
             // follow its last position in case the run ends exactly at this chunk's end
             if (valid && (lane == 63 || p + 1 == n)) {
                 const uint32_t p1 = base32 + static_cast<uint32_t>(j) + 1u;
+                if (wide) {  // the open run's symbol: its mark moves to this chunk's last position
+                    const uint32_t old1 = pr[c].x;
+                    if (old1 > base32) bm[(old1 - 1u - base32) >> 6] &= ~(1ull << ((old1 - 1u - base32) & 63u));
+                    bm[chunk] = 1ull << lane;
+                }
                 pos[tab_index(c)] = p1;
                 pr[c] = make_uint2(p1, r);
             }
@@ -238,7 +248,18 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
         const bool isB = start && prevsame < 0;
         // ---- case A: distinct symbols in lanes (w, lane)
         uint32_t cnt = 0;
-        {
+        uint64_t mA = __ballot(isA);
+        if (__popcll(mA) <= DC_FEW_A) {
+            // few such lanes (large alphabets): one ballot each -- the lanes that are first of their symbol after w, cut to (w, lane)
+            while (mA) {
+                const int bit = __builtin_ctzll(mA);
+                mA &= mA - 1;
+                const int w = __builtin_amdgcn_readlane(prevsame, bit);
+                const uint64_t firsts = __ballot(valid && prevsame <= w);
+                const uint64_t window = ((1ull << bit) - 1ull) & ~((2ull << w) - 1ull);  // lanes w+1 .. bit-1
+                cnt = write_lane(static_cast<uint32_t>(__popcll(firsts & window)), bit, cnt);
+            }
+        } else {
             const int w = prevsame;
             int sh = prevsame;
             for (int t = 1; t < 64; ++t) {
@@ -251,7 +272,44 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
         // ---- case B: first occurrence of the symbol in this chunk; the previous one (if any) is in the table
         const bool first_here = valid && prevsame < 0;
         uint64_t mB = __ballot(isB);
-        if (__popcll(mB) > DC_WIDE_B) {
+        if (chunk == 0) wide = __popcll(__ballot(first_here)) > DC_WIDE_B;
+        if (wide && chunk > 0 && __popcll(mB) > DC_WIDE_B) {
+            // Wide tile (large alphabet), previous occurrence b inside the tile: the distinct symbols in (b, chunk start) are the marked
+            // positions of the tile bitmap in that range -- a prefix popcount, two cross-lane fetches -- plus the symbols first seen in
+            // this chunk before the lane whose previous occurrence is not after b (the same short loop as below, but lane-parallel in
+            // the other direction).  Lanes whose previous occurrence lies before the tile take the scalar route.
+            const uint32_t b1 = tab.x;
+            const bool in_tile = b1 > base32;
+            const unsigned long long w = bm[lane];
+            const uint32_t pc = static_cast<uint32_t>(__popcll(w));
+            const uint32_t incl = wave_incl_sum(pc, lane);
+            const uint32_t total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+            const uint32_t lo = in_tile ? b1 - base32 : 0u;  // tile index of the first position after b
+            const int word = static_cast<int>(lo >> 6);
+            const unsigned long long mw = (static_cast<unsigned long long>(static_cast<uint32_t>(__shfl(static_cast<int>(w >> 32), word, 64))) << 32) |
+                                          static_cast<uint32_t>(__shfl(static_cast<int>(w), word, 64));
+            const uint32_t pw = static_cast<uint32_t>(__shfl(static_cast<int>(incl - pc), word, 64));
+            const uint32_t below = pw + static_cast<uint32_t>(__popcll(mw & ((1ull << (lo & 63u)) - 1ull)));
+            uint32_t rk = total - below;
+            uint64_t fm = __ballot(first_here);
+            while (fm) {
+                const int bit = __builtin_ctzll(fm);
+                fm &= fm - 1;
+                const uint32_t tq = __builtin_amdgcn_readlane(tab.x, bit);
+                rk += (bit < lane && tq <= b1) ? 1u : 0u;
+            }
+            if (isB) cnt = in_tile ? rk : 0u;
+            uint64_t slow = __ballot(isB && b1 != 0 && !in_tile);
+            while (slow) {
+                const int bit = __builtin_ctzll(slow);
+                slow &= slow - 1;
+                const uint32_t sb1 = __builtin_amdgcn_readlane(tab.x, bit);
+                uint32_t srk = static_cast<uint32_t>(__popcll(__ballot(mine.x > sb1)) + __popcll(__ballot(mine.y > sb1)) +
+                                                     __popcll(__ballot(mine.z > sb1)) + __popcll(__ballot(mine.w > sb1)));
+                srk += static_cast<uint32_t>(__popcll(__ballot(first_here && tab.x <= sb1) & ((1ull << bit) - 1ull)));
+                cnt = write_lane(srk, bit, cnt);
+            }
+        } else if (__popcll(mB) > DC_WIDE_B) {
             // many first occurrences (large alphabets: random bytes have ~57 per chunk): every lane counts for itself -- the 256 table
             // positions arrive as 64 broadcast 16-byte LDS reads, then the symbols first seen earlier in this chunk
             const uint32_t b1 = tab.x;
@@ -304,7 +362,13 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
         }
         // ---- table update: the last lane of every symbol of this chunk
         __builtin_amdgcn_wave_barrier();
-        if (valid && (same & ~le) == 0) {
+        const bool last_here = valid && (same & ~le) == 0;
+        if (wide) {  // marks of the symbols of this chunk move to their last lane here
+            if (last_here && tab.x > base32) atomicAnd(&bm[(tab.x - 1u - base32) >> 6], ~(1ull << ((tab.x - 1u - base32) & 63u)));
+            const uint64_t lm = __ballot(last_here);
+            if (lane == 0) bm[chunk] = lm;
+        }
+        if (last_here) {
             const uint32_t p1 = base32 + static_cast<uint32_t>(j) + 1u;
             const uint32_t run1 = r0 + static_cast<uint32_t>(__popcll(S & le));  // (index of the run holding this lane) + 1
             pos[tab_index(c)] = p1;
