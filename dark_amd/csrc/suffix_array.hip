@@ -277,7 +277,6 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
     __shared__ uint64_t s_key[RR_TILE + 2];                       // later reused: compacted idx | pos
     __shared__ __attribute__((aligned(16))) uint32_t s_idx[RR_TILE];
     __shared__ __attribute__((aligned(16))) uint32_t s_pos[RR_TILE];
-    __shared__ uint32_t s_ogid[RR_TILE];
     __shared__ __attribute__((aligned(8))) uint8_t s_flag[RR_TILE];
     __shared__ uint32_t s_tmp[RR_WAVES + 1];
     const int tid = threadIdx.x;
@@ -311,6 +310,8 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
         my_idx[0] = i0.x; my_idx[1] = i0.y; my_idx[2] = i0.z; my_idx[3] = i0.w; my_idx[4] = i1.x; my_idx[5] = i1.y; my_idx[6] = i1.z; my_idx[7] = i1.w;
         my_pos[0] = p0.x; my_pos[1] = p0.y; my_pos[2] = p0.z; my_pos[3] = p0.w; my_pos[4] = p1.x; my_pos[5] = p1.y; my_pos[6] = p1.z; my_pos[7] = p1.w;
     }
+    __syncthreads();              // every thread holds its slice of s_idx in registers:
+    uint32_t *s_ogid = s_idx;     // the array now collects the compacted group ids (35 KiB of LDS: four workgroups per CU)
 #pragma unroll
     for (int j = 0; j < RR_IPT; ++j) {
         const size_t a = a0 + j;
