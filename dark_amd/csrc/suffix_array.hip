@@ -268,6 +268,8 @@ __global__ __launch_bounds__(1024) void k_rerank_scan(RerankAgg *__restrict__ ag
 
 // pos_in == nullptr means slot a sits at SA position a (first rerank, straight after the initial sort).
 // All tile inputs arrive through LDS with lane-contiguous loads; the compacted outputs leave through LDS the same way.
+// FIRST = (pos_in == nullptr): no position array to stage, 8 KiB of LDS less -> more workgroups per CU for the largest launch
+template <bool FIRST>
 __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx,
                                                             const uint32_t *__restrict__ pos_in, size_t count, int gshift,
                                                             const RerankAgg *__restrict__ agg, uint32_t *__restrict__ rank,
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
                                                             uint32_t *__restrict__ gstart, uint32_t *__restrict__ headpos_out) {
     __shared__ uint64_t s_key[RR_TILE + 2];                       // later reused: compacted idx | pos
     __shared__ __attribute__((aligned(16))) uint32_t s_idx[RR_TILE];
-    __shared__ __attribute__((aligned(16))) uint32_t s_pos[RR_TILE];
+    __shared__ __attribute__((aligned(16))) uint32_t s_pos[FIRST ? 4 : RR_TILE];
     __shared__ __attribute__((aligned(8))) uint8_t s_flag[RR_TILE];
     __shared__ uint32_t s_tmp[RR_WAVES + 1];
     const int tid = threadIdx.x;
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
         const size_t a = b0 + o;
         if (a < count) {
             s_idx[o] = idx[a];
-            s_pos[o] = pos_in ? pos_in[a] : static_cast<uint32_t>(a);
+            if (!FIRST) s_pos[o] = pos_in[a];
         }
     }
     stage_flags(keys, count, b0, gshift, s_key, s_flag);  // ends with a barrier: s_idx / s_pos are visible, s_key is free
@@ -305,10 +307,17 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
     uint32_t *s_opos = s_oidx + RR_TILE;
     uint32_t my_idx[RR_IPT], my_pos[RR_IPT];
     {
-        const uint4 *pi = reinterpret_cast<const uint4 *>(s_idx + tid * RR_IPT), *pp = reinterpret_cast<const uint4 *>(s_pos + tid * RR_IPT);
-        const uint4 i0 = pi[0], i1 = pi[1], p0 = pp[0], p1 = pp[1];
+        const uint4 *pi = reinterpret_cast<const uint4 *>(s_idx + tid * RR_IPT);
+        const uint4 i0 = pi[0], i1 = pi[1];
         my_idx[0] = i0.x; my_idx[1] = i0.y; my_idx[2] = i0.z; my_idx[3] = i0.w; my_idx[4] = i1.x; my_idx[5] = i1.y; my_idx[6] = i1.z; my_idx[7] = i1.w;
-        my_pos[0] = p0.x; my_pos[1] = p0.y; my_pos[2] = p0.z; my_pos[3] = p0.w; my_pos[4] = p1.x; my_pos[5] = p1.y; my_pos[6] = p1.z; my_pos[7] = p1.w;
+        if (FIRST) {
+#pragma unroll
+            for (int j = 0; j < RR_IPT; ++j) my_pos[j] = static_cast<uint32_t>(a0) + j;  // slot a sits at SA position a
+        } else {
+            const uint4 *pp = reinterpret_cast<const uint4 *>(s_pos + tid * RR_IPT);
+            const uint4 p0 = pp[0], p1 = pp[1];
+            my_pos[0] = p0.x; my_pos[1] = p0.y; my_pos[2] = p0.z; my_pos[3] = p0.w; my_pos[4] = p1.x; my_pos[5] = p1.y; my_pos[6] = p1.z; my_pos[7] = p1.w;
+        }
     }
     __syncthreads();              // every thread holds its slice of s_idx in registers:
     uint32_t *s_ogid = s_idx;     // the array now collects the compacted group ids (35 KiB of LDS: four workgroups per CU)
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
         const uint32_t suffix = my_idx[j];
         // SA position of the group's head: the head slot is in this tile (LDS) or in an earlier one (global, rare)
         const size_t hs = el >> 1;
-        const uint32_t head_pos = !pos_in ? static_cast<uint32_t>(hs) : (hs >= b0 ? s_pos[hs - b0] : pos_in[hs]);
+        const uint32_t head_pos = FIRST ? static_cast<uint32_t>(hs) : (hs >= b0 ? s_pos[hs - b0] : pos_in[hs]);
         if (headpos_out) headpos_out[a] = head_pos;  // first rerank of a large block: ranks are stored by the bucketed scatter
         else if (rank && !(el & 1u)) rank[suffix] = head_pos;  // members of a group that kept its head keep their rank: no scatter
         if (!(f & F_SURV)) {
@@ -373,7 +382,10 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
     }
     {
         LaunchScope ls(ctx, K_RERANK_APPLY, 8.0 * count + 4.0 * count + 4.0 * count + 12.0 * count);
-        k_rerank_apply<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gshift, agg, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out);
+        if (pos_in)
+            k_rerank_apply<false><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gshift, agg, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out);
+        else
+            k_rerank_apply<true><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gshift, agg, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out);
     }
     DK_HIP(ctx, hipGetLastError());
     ctx->ws_release(mark);
