@@ -338,6 +338,7 @@ template <class M, class E>
 int write_stream(M &model, const DcStream &s, E &e) {
     const size_t n = s.n;
     auto code = [&](uint32_t v, uint8_t sym) { return model.encode(v, sym, e); };
+    auto fail = [&] { return e.error() ? e.error() : DK_E_MODEL; };  // the sink's own error (capacity) wins over "the model refused"
     // Init-table RLE: alternating present / absent run lengths over symbols 0..254; every present symbol is followed
     // by its first position.  The first present-run length is raw, all later lengths are len-1.  Symbol 0xFF is
     // never visited (all loops stop at 0xFF): blocks containing byte 0xFF encode, but cannot be decoded.
@@ -347,19 +348,19 @@ int write_stream(M &model, const DcStream &s, E &e) {
         const size_t base = i;
         if (active) {
             while (i < 0xFF && s.init[i] < n) ++i;
-            if (!code(static_cast<uint32_t>(base == 0 ? i : i - base - 1), 0)) return DK_E_MODEL;
+            if (!code(static_cast<uint32_t>(base == 0 ? i : i - base - 1), 0)) return fail();
             for (size_t c = base; c < i; ++c)
-                if (!code(s.init[c], static_cast<uint8_t>(c))) return DK_E_MODEL;
+                if (!code(s.init[c], static_cast<uint8_t>(c))) return fail();
             active = false;
         } else {
             do { ++i; } while (i < 0xFF && s.init[i] == n);
-            if (!code(static_cast<uint32_t>(i - base - 1), 0)) return DK_E_MODEL;
+            if (!code(static_cast<uint32_t>(i - base - 1), 0)) return fail();
             active = true;
         }
     }
     for (size_t k = 0; k < s.m; ++k)  // src/block/dc.rs:82-85
-        if (!code(s.dist[k], s.sym[k])) return e.error() ? e.error() : DK_E_MODEL;
-    if (!code(s.origin, 0)) return e.error() ? e.error() : DK_E_MODEL;  // src/block/dc.rs:88 under CTX_0
+        if (!code(s.dist[k], s.sym[k])) return fail();
+    if (!code(s.origin, 0)) return fail();  // src/block/dc.rs:88 under CTX_0
     if (!e.finish()) return e.error();
     return DK_OK;
 }

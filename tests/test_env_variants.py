@@ -23,6 +23,35 @@ for m in ("dark", "exp", "ybs", "simple"):
 print("ok")
 """
 
+# error paths of the two-thread coder: the coding thread runs out of output space / the model thread refuses a distance; both must
+# come back as return codes (no hang: the side that fails keeps the ring moving until the other one has ended)
+CPU_ERROR_SNIPPET = r"""
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, %r)
+from dark_amd import _lib, datagen
+from oracle import orc
+lib = _lib.load()
+t = datagen.wiki_like(300000, 6)
+bwt, origin = orc.bwt_forward(t)
+dc = orc.dc_encode(bwt)
+init = np.ascontiguousarray(dc["init"], np.uint32); d = np.ascontiguousarray(dc["d"], np.uint32); s = np.ascontiguousarray(dc["sym"], np.uint8)
+def call(dist, cap):
+    out = np.empty(max(cap, 1), np.uint8); ln = C.c_size_t(0)
+    return lib.dk_stream_encode(0, len(t), init.ctypes.data, dist.ctypes.data, s.ctypes.data, None, None, len(dist), int(origin),
+                                out.ctypes.data, cap, C.byref(ln)), ln.value
+rc, ln = call(d, 8 * len(d) + 8192)
+assert rc == 0 and ln > 1000
+for cap in (0, 3, 100, ln // 2, ln - 1):
+    rc2, _ = call(d, cap)
+    assert rc2 == _lib.DK_E_CAPACITY, (cap, rc2)
+bad = d.copy(); bad[len(bad) // 2] = 0x7FFFFFFF
+rc3, _ = call(bad, 8 * len(d) + 8192)
+assert rc3 == _lib.DK_E_MODEL, rc3
+rc4, ln4 = call(d, ln)   # exactly enough
+assert rc4 == 0 and ln4 == ln
+print("ok")
+"""
+
 GPU_SNIPPET = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)
@@ -90,6 +119,11 @@ def _run(snippet, env):
 def test_two_thread_entropy_is_bit_exact():
     _run(CPU_SNIPPET, {"DK_ENTROPY_THREADS": "2"})
     _run(CPU_SNIPPET, {"DK_ENTROPY_THREADS": "1"})
+
+
+@pytest.mark.parametrize("threads", ["1", "2"])
+def test_entropy_error_paths_return_codes(threads):
+    _run(CPU_ERROR_SNIPPET, {"DK_ENTROPY_THREADS": threads})
 
 
 @pytest.mark.gpu
