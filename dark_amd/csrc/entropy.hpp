@@ -10,6 +10,9 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#if defined(__SSE4_1__)
+#include <immintrin.h>
+#endif
 
 #include "../../include/dark_amd.h"
 
@@ -251,6 +254,97 @@ struct FreqTable {
         return d.take(lo, hi);
     }
 };
+
+#if defined(__SSE4_1__)
+// The 8-entry tables of the dark model as one 16-byte vector.  Same arithmetic, but every update is a whole-vector store and every
+// read a whole-vector load: the same table is updated for one distance and read again for the next, and a 16-byte load that follows
+// a 2-byte store to the same line cannot be forwarded from the store buffer (it waits for the store to retire).
+namespace simd8 {
+alignas(16) inline constexpr uint16_t kOneHot[8][8] = {{0xFFFF, 0, 0, 0, 0, 0, 0, 0}, {0, 0xFFFF, 0, 0, 0, 0, 0, 0}, {0, 0, 0xFFFF, 0, 0, 0, 0, 0},
+                                                      {0, 0, 0, 0xFFFF, 0, 0, 0, 0}, {0, 0, 0, 0, 0xFFFF, 0, 0, 0}, {0, 0, 0, 0, 0, 0xFFFF, 0, 0},
+                                                      {0, 0, 0, 0, 0, 0, 0xFFFF, 0}, {0, 0, 0, 0, 0, 0, 0, 0xFFFF}};
+alignas(16) inline constexpr uint16_t kBelow[9][8] = {{0, 0, 0, 0, 0, 0, 0, 0},
+                                                     {0xFFFF, 0, 0, 0, 0, 0, 0, 0},
+                                                     {0xFFFF, 0xFFFF, 0, 0, 0, 0, 0, 0},
+                                                     {0xFFFF, 0xFFFF, 0xFFFF, 0, 0, 0, 0, 0},
+                                                     {0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0, 0, 0, 0},
+                                                     {0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0, 0, 0},
+                                                     {0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0, 0},
+                                                     {0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0},
+                                                     {0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF}};
+inline __m128i one_hot(size_t v) { return _mm_load_si128(reinterpret_cast<const __m128i *>(kOneHot[v])); }
+inline __m128i below(size_t v) { return _mm_load_si128(reinterpret_cast<const __m128i *>(kBelow[v])); }
+// sum of the eight 16-bit lanes; every lane must be below 2^15 (all frequencies here are below 2^14)
+inline uint32_t hsum(__m128i x) {
+    __m128i s = _mm_madd_epi16(x, _mm_set1_epi16(1));
+    s = _mm_add_epi32(s, _mm_shuffle_epi32(s, 0x4E));
+    s = _mm_add_epi32(s, _mm_shuffle_epi32(s, 0xB1));
+    return static_cast<uint32_t>(_mm_cvtsi128_si32(s));
+}
+}  // namespace simd8
+
+template <>
+struct FreqTable<8> {
+    alignas(16) uint16_t f[8];
+    uint32_t total;
+    __m128i vec() const { return _mm_load_si128(reinterpret_cast<const __m128i *>(f)); }
+    void set(__m128i v) { _mm_store_si128(reinterpret_cast<__m128i *>(f), v); }
+    void flat() { set(_mm_set1_epi16(1)); total = 8; while (total >= kModelThreshold) halve(); }
+    void halve() {
+        const __m128i h = _mm_srli_epi16(_mm_add_epi16(vec(), _mm_set1_epi16(1)), 1);
+        set(h);
+        total = simd8::hsum(h);
+    }
+    inline void bump(size_t v, unsigned add_log, uint32_t add_const) {
+        const uint32_t add = (total >> add_log) + add_const;
+        set(_mm_add_epi16(vec(), _mm_and_si128(simd8::one_hot(v), _mm_set1_epi16(static_cast<short>(add)))));
+        total += add;
+        if (total >= kModelThreshold) halve();
+    }
+    inline uint32_t below(size_t v) const { return simd8::hsum(_mm_and_si128(vec(), simd8::below(v))); }
+    template <class E> bool encode(E &e, size_t v) const { const uint32_t lo = below(v); return e.put(total, lo, lo + f[v]); }
+    bool decode(Decoder &d, size_t &v) const {
+        d.begin(total);
+        if (d.error()) return false;
+        uint32_t lo = 0, hi = f[0];
+        size_t k = 0;
+        while (!d.below(hi)) {
+            if (++k >= 8) return d.fail(DK_E_STREAM);
+            lo = hi;
+            hi += f[k];
+        }
+        v = k;
+        return d.take(lo, hi);
+    }
+};
+
+template <class E>
+inline bool encode_mix12(E &e, const FreqTable<8> &a, const FreqTable<8> &b, size_t v) {
+    const __m128i bv = b.vec();
+    const __m128i w = _mm_add_epi16(a.vec(), _mm_add_epi16(bv, bv));  // a + 2 b per symbol, below 3 * 2^12 + slack
+    const uint32_t lo = simd8::hsum(_mm_and_si128(w, simd8::below(v)));
+    const uint32_t fv = simd8::hsum(_mm_and_si128(w, simd8::one_hot(v)));
+    return e.put(a.total + 2u * b.total, lo, lo + fv);
+}
+inline bool decode_mix12(Decoder &d, const FreqTable<8> &a, const FreqTable<8> &b, size_t &v) {
+    d.begin(a.total + 2u * b.total);
+    if (d.error()) return false;
+    const __m128i bv = b.vec();
+    __m128i w = _mm_add_epi16(a.vec(), _mm_add_epi16(bv, bv));
+    w = _mm_add_epi16(w, _mm_slli_si128(w, 2));  // inclusive prefix sums of the eight lanes (the last one is the total, < 2^16)
+    w = _mm_add_epi16(w, _mm_slli_si128(w, 4));
+    w = _mm_add_epi16(w, _mm_slli_si128(w, 8));
+    alignas(16) uint16_t incl[8];
+    _mm_store_si128(reinterpret_cast<__m128i *>(incl), w);
+    // symbol = number of cumulative borders at or below the offset: x >= r * incl[i], i = 0..6 (x < r * incl[7] was checked by begin())
+    const uint64_t x = d.x(), r = d.r();
+    size_t k = 0;
+#pragma GCC unroll 8
+    for (int i = 0; i < 7; ++i) k += x >= r * incl[i] ? 1u : 0u;
+    v = k;
+    return d.take(k ? incl[k - 1] : 0u, incl[k]);
+}
+#endif
 
 // table::SumProxy::new(1, a, 2, b, 0): the only weighting the reference uses (dark.rs:194,243)
 template <int N, class E>
