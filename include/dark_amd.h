@@ -132,7 +132,7 @@ typedef struct dk_stats {
     uint32_t sort_passes;     /* radix passes executed by the last suffix sort */
     uint64_t sorted_elements; /* sum over passes of elements moved */
     uint64_t dc_runs;         /* m of the last dc encode */
-    uint32_t entropy_threads; /* host threads the last range-coder pass used: 1, or 2 (models | coder on two cores of one L3) */
+    uint32_t entropy_threads; /* host threads the last range-coder pass used: 1, 2 (models | coder) or 4 (two model halves, merger, coder) */
     uint32_t reserved0;
     /* per-kernel HIP-event timings accumulated since dk_stats_reset (only while profiling is enabled) */
     uint32_t kernel_launches[DK_NUM_KERNEL_SLOTS];

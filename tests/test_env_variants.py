@@ -1,5 +1,5 @@
 """Alternative code paths selected by environment variables (read once per process, hence subprocesses):
-DK_ENTROPY_THREADS=2 (models and coder on two host threads), DK_SORT=onesweep (single-kernel look-back radix passes),
+DK_ENTROPY_THREADS=2|4 (models | coder on two host threads, the four-stage pipeline of the dark model), DK_SORT=onesweep (single-kernel look-back radix passes),
 DK_BUCKETED=0 / DK_XCD=0 (plain rank scatter / plain tile order).  Every variant must give the same bytes."""
 import os
 import subprocess
@@ -116,12 +116,13 @@ def _run(snippet, env):
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
 
-def test_two_thread_entropy_is_bit_exact():
+def test_multi_thread_entropy_is_bit_exact():
+    _run(CPU_SNIPPET, {"DK_ENTROPY_THREADS": "4"})
     _run(CPU_SNIPPET, {"DK_ENTROPY_THREADS": "2"})
     _run(CPU_SNIPPET, {"DK_ENTROPY_THREADS": "1"})
 
 
-@pytest.mark.parametrize("threads", ["1", "2"])
+@pytest.mark.parametrize("threads", ["1", "2", "4"])
 def test_entropy_error_paths_return_codes(threads):
     _run(CPU_ERROR_SNIPPET, {"DK_ENTROPY_THREADS": threads})
 

@@ -36,6 +36,22 @@ int main(){
         p+=nb; ++nev;
     }
     double t2=now_ms();
+    {   // uniform events: every decision as (from, to, 2^64 / total rounded up) -> no division, no shift/divide branch in the coder
+        struct UEv { uint64_t inv; uint32_t from, to; };
+        std::vector<UEv> ue; ue.reserve(nev);
+        for (size_t k=0;k<cnt;) { const uint32_t u=ev[k];
+            if (u&0x8000u){ const uint32_t zero=u&0xFFFu; const bool one=(u&0x4000u)!=0; ue.push_back({1ull<<52, one?zero:0u, one?4096u:zero}); k+=1; }
+            else { const uint32_t total=ev[k+2]; ue.push_back({(total&(total-1))? (~0ull/total+1) : ((1ull<<63)/total*2), u, ev[k+1]}); k+=3; } }
+        RangeState r2; uint8_t *q = out.data();
+        double u0=now_ms();
+        for (const UEv &x : ue) {
+            const uint32_t span=r2.hi-r2.low;
+            const uint32_t rr=static_cast<uint32_t>((static_cast<unsigned __int128>(span)*x.inv)>>64);
+            q += r2.narrow(rr, x.from, x.to, q);
+        }
+        double u1=now_ms();
+        printf("   uniform coder: %.1f ms %.2f ns/dist, out %zu bytes (%s)\n", u1-u0,(u1-u0)*1e6/m,(size_t)(q-out.data()), (size_t)(q-out.data())==(size_t)(p-out.data())?"same":"DIFFERENT");
+    }
     {   // model halves alone
         struct ExpSide { DarkModel &m; bool encode(uint32_t dist, uint8_t sym, VecSink &e) { return m.encode_exponent(dist, sym, e); } };
         struct ManSide { DarkModel &m; bool encode(uint32_t dist, uint8_t, VecSink &e) { return m.encode_mantissa_modelled(dist, e); } };
