@@ -10,8 +10,12 @@
 #include <thread>
 #include <vector>
 #if defined(__linux__)
+#include <fcntl.h>
 #include <pthread.h>
 #include <sched.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #endif
 
 namespace dk {
@@ -532,7 +536,7 @@ private:
     static constexpr uint32_t kFull = 0x40000000u;
     static void backoff(unsigned &spins) {
         // busy-wait: a hand-off is expected every few microseconds; yielding to the scheduler costs far more than that
-        if (++spins < (1u << 20)) {
+        if (++spins < (1u << 14)) {  // ~0.5 ms of pauses, then let the scheduler run whoever we are waiting for
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
@@ -700,21 +704,32 @@ std::vector<int> read_cpu_list(const std::string &path) {
     std::fclose(f);
     return out;
 }
-// The CPUs that share the last-level cache with `me` and that this thread may run on.  Returns the number of physical cores among
-// them (exact when whole cores are allowed, the usual case), 0 when `me` itself is not usable.
-int l3_group(int me, const cpu_set_t &allowed, cpu_set_t *group) {
-    const std::string base = "/sys/devices/system/cpu/cpu" + std::to_string(me);
-    const std::vector<int> l3 = read_cpu_list(base + "/cache/index3/shared_cpu_list");
-    const size_t threads_per_core = std::max<size_t>(1, read_cpu_list(base + "/topology/thread_siblings_list").size());
-    CPU_ZERO(group);
-    size_t cpus = 0;
-    for (int c : l3) {
-        if (c < 0 || c >= CPU_SETSIZE || !CPU_ISSET(c, &allowed)) continue;
-        CPU_SET(c, group);
-        ++cpus;
-    }
-    if (!CPU_ISSET(me, group)) return 0;
-    return static_cast<int>((cpus + threads_per_core - 1) / threads_per_core);
+// The machine's last-level-cache groups (one per CCX on EPYC), read once from sysfs.
+struct L3Group { int id; cpu_set_t cpus; };
+struct Topology { std::vector<L3Group> groups; size_t threads_per_core = 1; };
+const Topology &topology() {
+    static const Topology topo = [] {
+        Topology t;
+        cpu_set_t seen;
+        CPU_ZERO(&seen);
+        int misses = 0;
+        for (int cpu = 0; cpu < CPU_SETSIZE && misses < 64; ++cpu) {  // (cpu numbers can have holes; 64 in a row is the end)
+            if (CPU_ISSET(cpu, &seen)) continue;
+            const std::string base = "/sys/devices/system/cpu/cpu" + std::to_string(cpu);
+            const std::vector<int> l3 = read_cpu_list(base + "/cache/index3/shared_cpu_list");
+            if (l3.empty()) { ++misses; continue; }  // no such cpu / no L3 information
+            misses = 0;
+            if (t.groups.empty()) t.threads_per_core = std::max<size_t>(1, read_cpu_list(base + "/topology/thread_siblings_list").size());
+            L3Group g;
+            g.id = l3.front();
+            CPU_ZERO(&g.cpus);
+            for (int c : l3)
+                if (c >= 0 && c < CPU_SETSIZE) { CPU_SET(c, &g.cpus); CPU_SET(c, &seen); }
+            t.groups.push_back(g);
+        }
+        return t;
+    }();
+    return topo;
 }
 #endif
 
@@ -724,18 +739,56 @@ int l3_group(int me, const cpu_set_t &allowed, cpu_set_t *group) {
 // (EPYC 9575F, ns per distance of a text block: one thread 22; two unpinned 38; two pinned 19, where the model thread is the slower
 // one -- so the dark model also moves its mantissa half to the coder's thread, see DarkCoderSide).
 // Returns DK_E_NODEVICE (reused as "not available") when no partner core can be pinned; the caller then codes on one thread.
+// The helper threads of one encode call and its caller are confined, for the duration of the call, to ONE last-level-cache group with
+// enough cores.  Groups are claimed across processes with an advisory lock (a file per group under /dev/shm, released by close or
+// process death): ranks started by one launcher tend to sit in the same CCX when their first block is ready, and two pipelines
+// spinning in one CCX would halve each other.  The caller's own group is tried first, then the others by distance; when every
+// group is taken the call gets none (and codes on one thread).  The caller's affinity mask is restored on release.
 struct ThreadPair {
     int me = -1;
 #if defined(__linux__)
     cpu_set_t saved, group;
+    int lock_fd = -1;
     bool acquire(int cores_needed = 2) {
         if (pthread_getaffinity_np(pthread_self(), sizeof(saved), &saved) != 0) return false;
-        me = sched_getcpu();
-        if (me < 0 || me >= CPU_SETSIZE || l3_group(me, saved, &group) < cores_needed) return false;
-        return pthread_setaffinity_np(pthread_self(), sizeof(group), &group) == 0;
+        const int cpu = sched_getcpu();
+        const Topology &topo = topology();
+        if (cpu < 0 || cpu >= CPU_SETSIZE || topo.groups.empty()) return false;
+        size_t own = topo.groups.size();
+        for (size_t g = 0; g < topo.groups.size(); ++g)
+            if (CPU_ISSET(cpu, &topo.groups[g].cpus)) own = g;
+        if (own == topo.groups.size()) return false;
+        for (size_t step = 0; step < 2 * topo.groups.size(); ++step) {  // own, own+1, own-1, own+2, ...
+            const long off = (step & 1) ? static_cast<long>((step + 1) / 2) : -static_cast<long>(step / 2);
+            const long gi = static_cast<long>(own) + off;
+            if (gi < 0 || gi >= static_cast<long>(topo.groups.size()) || (step > 0 && off == 0)) continue;
+            const L3Group &g = topo.groups[static_cast<size_t>(gi)];
+            cpu_set_t usable;
+            CPU_AND(&usable, &g.cpus, &saved);
+            const size_t cores = (static_cast<size_t>(CPU_COUNT(&usable)) + topo.threads_per_core - 1) / topo.threads_per_core;
+            if (cores < static_cast<size_t>(cores_needed)) continue;
+            const std::string path = "/dev/shm/dark_amd.l3." + std::to_string(g.id) + ".lock";
+            const int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+            if (fd >= 0) {
+                (void)fchmod(fd, 0666);  // other users' processes must be able to take part
+                if (flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); continue; }  // another pipeline lives here
+            } else if (gi != static_cast<long>(own)) {
+                continue;  // cannot coordinate: stay at home rather than crowd somebody else's group
+            }
+            if (pthread_setaffinity_np(pthread_self(), sizeof(usable), &usable) != 0) { if (fd >= 0) close(fd); continue; }
+            group = usable;
+            lock_fd = fd;
+            me = g.id;
+            return true;
+        }
+        return false;
     }
     void pin_partner() const { (void)pthread_setaffinity_np(pthread_self(), sizeof(group), &group); }
-    void release() { (void)pthread_setaffinity_np(pthread_self(), sizeof(saved), &saved); }
+    void release() {
+        (void)pthread_setaffinity_np(pthread_self(), sizeof(saved), &saved);
+        if (lock_fd >= 0) close(lock_fd);
+        lock_fd = -1;
+    }
 #else
     bool acquire(int = 2) { return false; }
     void pin_partner() const {}
@@ -853,7 +906,7 @@ public:
 private:
     static constexpr uint32_t kFull = 0x40000000u;
     static void backoff(unsigned &spins) {
-        if (++spins < (1u << 20)) {
+        if (++spins < (1u << 14)) {  // ~0.5 ms of pauses, then let the scheduler run whoever we are waiting for
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
