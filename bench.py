@@ -58,8 +58,26 @@ def make_block(workload, seed_offset, n_override):
     return fn(n, seed + seed_offset)
 
 
+def cpu_budget():
+    """CPUs this container may use (cgroup quota; os.cpu_count() when unlimited)."""
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            return max(1, int(q) // int(period))
+    except (OSError, ValueError):
+        pass
+    return os.cpu_count() or 1
+
+
 def main():
     args = parse()
+    # Host threads: the ranks of one node share the container's CPU quota.  The single-block encoder busy-waits on up to four cores
+    # per rank; tell the library to stay within this rank's share (it reads DK_ENTROPY_THREADS once, when it is loaded).
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    share = max(1, cpu_budget() // max(1, local_world))
+    if "DK_ENTROPY_THREADS" not in os.environ and share < 4:
+        os.environ["DK_ENTROPY_THREADS"] = "2" if share >= 2 else "1"
+    args.pipeline_threads = max(1, min(args.pipeline_threads, share - 1))
     import torch
     import torch.distributed as dist
     import dark_amd
@@ -266,7 +284,7 @@ def main():
             "compressed_bytes": int(len(stream)), "ratio": round(len(stream) / n, 4),
             "stage_ms": {kk: round(v, 3) for kk, v in per.items()},
             "sa_rounds": stats["rounds"], "sort_passes": stats["sort_passes"], "dc_runs": stats["dc_runs"],
-            "host_entropy_threads": stats["entropy_threads"],
+            "host_entropy_threads": stats["entropy_threads"], "host_cpu_share_per_rank": share,
             "kernel_ms_per_step": {kk: round(v["ms"] / k, 3) for kk, v in sorted(kern.items(), key=lambda x: -x[1]["ms"])},
             "roofline": roofline,
             "bwt_forward_roofline": fwd_roofline,

@@ -1123,6 +1123,29 @@ int encode_four_stages(DarkModel &model, const DcStream &s, uint8_t *out, size_t
 template <class M>
 int encode_four_stages(M &, const DcStream &, uint8_t *, size_t, size_t *) { return DK_E_NODEVICE; }  // only the dark model splits this way
 
+// CPUs this process may burn according to its cgroup (v2 cpu.max, v1 cfs quota); a huge number when unlimited or unknown.  The
+// pipeline stages busy-wait, so a pipeline wider than the quota would only be throttled.
+int cgroup_cpu_budget() {
+    static const int budget = [] {
+        long long quota = -1, period = 100000;
+        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64];
+            if (std::fscanf(f, "%63s %lld", q, &period) >= 1 && q[0] != 'm') quota = std::atoll(q);
+            std::fclose(f);
+        } else if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (std::fscanf(g, "%lld", &quota) != 1) quota = -1;
+            std::fclose(g);
+            if (FILE *h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (std::fscanf(h, "%lld", &period) != 1) period = 100000;
+                std::fclose(h);
+            }
+        }
+        if (quota <= 0 || period <= 0) return 1 << 20;
+        return static_cast<int>(std::max<long long>(1, quota / period));
+    }();
+    return budget;
+}
+
 // 0 = automatic, 1 = one thread, 2 = models | coder, 4 = the four-stage pipeline (dark model), each whenever the cores exist
 int entropy_thread_mode() {
     static const int mode = [] { const char *e = getenv("DK_ENTROPY_THREADS"); return e ? atoi(e) : 0; }();
@@ -1143,12 +1166,13 @@ int encode_block_stream(int model_id, const DcStream &s, uint8_t *out, size_t ca
         const int mode = host_threads ? host_threads : entropy_thread_mode();
         t_last_threads = 1;
         const bool large = s.m >= (1u << 21);
-        if (mode == 4 || (mode == 0 && large)) {
+        const int budget = cgroup_cpu_budget();
+        if (mode == 4 || (mode == 0 && large && budget >= 4)) {
             const int rc4 = encode_four_stages(model, s, out, cap, out_len);
             if (rc4 != DK_E_NODEVICE) { t_last_threads = 4; return rc4; }
             model.reset();  // not this model, or fewer than four cores: try two threads
         }
-        if (mode == 2 || mode == 4 || (mode == 0 && large)) {
+        if (mode == 2 || mode == 4 || (mode == 0 && large && budget >= 2)) {
             const int rc2 = encode_two_threads(model, s, out, cap, out_len);
             if (rc2 != DK_E_NODEVICE) { t_last_threads = 2; return rc2; }
             model.reset();  // no partner core: fall through to the single-thread coder
