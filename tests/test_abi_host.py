@@ -166,3 +166,18 @@ def test_property_model_streams(orc):
         assert (model.decode(m, got, sym) == d).all()
 
     check()
+
+
+def test_reciprocal_division_is_exact():
+    """The four-stage encoder replaces r = span / total by the high half of span * ceil(2^64 / total) (entropy.cpp, UEvent).  The claim:
+    exact for every span < 2^32 and total in [2, 2^15).  Checked here for every total against edge spans and random ones."""
+    import random
+    rng = random.Random(5)
+    for total in range(2, 1 << 15):
+        inv = (((1 << 64) - 1) // total + 1) if total & (total - 1) else ((1 << 63) // total * 2)
+        assert inv == -(-(1 << 64) // total)  # ceil(2^64 / total), as the C code computes it
+        spans = [0, 1, total - 1, total, total + 1, (1 << 32) - 1, (1 << 32) - total, ((1 << 32) // total) * total - 1,
+                 ((1 << 32) // total) * total] + [rng.randrange(1 << 32) for _ in range(6)]
+        for span in spans:
+            if 0 <= span < (1 << 32):
+                assert (span * inv) >> 64 == span // total, (span, total)
