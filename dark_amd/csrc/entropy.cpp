@@ -733,12 +733,10 @@ const Topology &topology() {
 }
 #endif
 
-// Models on a second thread, range coder on the calling one.  Both are confined (the caller's mask is restored) to the cores that
-// share the caller's L3 -- the whole group rather than two fixed cores, so that the scheduler can still step around a core another
-// process is using: unconfined, the two threads tend to land on different CCDs and the hand-off costs more than the split saves
-// (EPYC 9575F, ns per distance of a text block: one thread 22; two unpinned 38; two pinned 19, where the model thread is the slower
-// one -- so the dark model also moves its mantissa half to the coder's thread, see DarkCoderSide).
-// Returns DK_E_NODEVICE (reused as "not available") when no partner core can be pinned; the caller then codes on one thread.
+// Host threads for one block.  Unconfined, helper and caller tend to land on different CCDs and every hand-off costs more than the
+// split saves (EPYC 9575F, ns per distance of a text block: one thread 22; two threads unconfined 38, confined to one L3 16-19).
+// The encode_* functions below return DK_E_NODEVICE (reused as "not available") when the cores cannot be had; the caller then falls
+// back to a narrower form.
 // The helper threads of one encode call and its caller are confined, for the duration of the call, to ONE last-level-cache group with
 // enough cores.  Groups are claimed across processes with an advisory lock (a file per group under /dev/shm, released by close or
 // process death): ranks started by one launcher tend to sit in the same CCX when their first block is ready, and two pipelines
