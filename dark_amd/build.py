@@ -32,6 +32,10 @@ def build(force=False, verbose=False):
         if force or not os.path.exists(op) or os.path.getmtime(op) < newest_dep:
             # host-only sources: x86-64-v3 (AVX2, BMI2, LZCNT, MOVBE) -- every host that carries an MI355X has it
             extra = ["-x", "hip"] if src.endswith(".hip") else ["-march=x86-64-v3"]
+            if src == "entropy.cpp":
+                # the models, the sinks and the coder are small functions calling each other once per coded decision: with the
+                # default threshold clang leaves some of them out of line (measured on the GPU box: 22.5 -> 19.5 ns per distance)
+                extra += ["-mllvm", "-inline-threshold=2000"]
             cmd = [HIPCC] + CXXFLAGS + extra + ["-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd), flush=True)
