@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libdark_amd.so")
+SO_PATH = os.environ.get("DARK_AMD_LIB") or os.path.join(HERE, "libdark_amd.so")  # DARK_AMD_LIB: another build of the same ABI (A/B runs)
 
 DK_OK = 0
 DK_E_ARG, DK_E_NOMEM, DK_E_HIP, DK_E_CAPACITY, DK_E_MODEL, DK_E_STREAM, DK_E_INTERNAL, DK_E_NODEVICE = -1, -2, -3, -4, -5, -6, -7, -8
