@@ -571,7 +571,7 @@ bool EventSink::finish() {
 namespace {
 
 // consumer side: the range coder over the recorded intervals
-int drain_pipe(EventPipe &pipe, uint8_t *out, size_t cap, size_t *out_len) {
+__attribute__((noinline)) int drain_pipe(EventPipe &pipe, uint8_t *out, size_t cap, size_t *out_len) {
     RangeState rs;
     size_t len = 0;
     int err = DK_OK;
@@ -1020,7 +1020,8 @@ struct DarkMergeSide {  // the order of dark.rs:180-232: table decision, unary e
 };
 
 // the calling thread: the range coder over ring U
-int code_uniform(URing &ring, uint8_t *out, size_t cap, size_t *out_len) {
+// (kept out of line: inlined into the callers' large bodies its loop lost registers to spills -- `low` went through the stack)
+__attribute__((noinline)) int code_uniform(URing &ring, uint8_t *out, size_t cap, size_t *out_len) {
     RangeState rs;
     size_t len = 0;
     int err = DK_OK;
