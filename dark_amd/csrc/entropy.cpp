@@ -705,7 +705,7 @@ std::vector<int> read_cpu_list(const std::string &path) {
     return out;
 }
 // The machine's last-level-cache groups (one per CCX on EPYC), read once from sysfs.
-struct L3Group { int id; cpu_set_t cpus; };
+struct L3Group { int id; cpu_set_t cpus; cpu_set_t primary; };  // primary: one hardware thread (the lowest numbered) of every core
 struct Topology { std::vector<L3Group> groups; size_t threads_per_core = 1; };
 const Topology &topology() {
     static const Topology topo = [] {
@@ -723,8 +723,14 @@ const Topology &topology() {
             L3Group g;
             g.id = l3.front();
             CPU_ZERO(&g.cpus);
-            for (int c : l3)
-                if (c >= 0 && c < CPU_SETSIZE) { CPU_SET(c, &g.cpus); CPU_SET(c, &seen); }
+            CPU_ZERO(&g.primary);
+            for (int c : l3) {
+                if (c < 0 || c >= CPU_SETSIZE) continue;
+                CPU_SET(c, &g.cpus);
+                CPU_SET(c, &seen);
+                const std::vector<int> sib = read_cpu_list("/sys/devices/system/cpu/cpu" + std::to_string(c) + "/topology/thread_siblings_list");
+                if (sib.empty() || *std::min_element(sib.begin(), sib.end()) == c) CPU_SET(c, &g.primary);
+            }
             t.groups.push_back(g);
         }
         return t;
@@ -761,10 +767,15 @@ struct ThreadPair {
             const long gi = static_cast<long>(own) + off;
             if (gi < 0 || gi >= static_cast<long>(topo.groups.size()) || (step > 0 && off == 0)) continue;
             const L3Group &g = topo.groups[static_cast<size_t>(gi)];
+            // one hardware thread per core where the caller's mask allows it: two stages of one pipeline on the two hardware
+            // threads of one core would share its execution units (seen as run-to-run swings of several percent)
             cpu_set_t usable;
-            CPU_AND(&usable, &g.cpus, &saved);
-            const size_t cores = (static_cast<size_t>(CPU_COUNT(&usable)) + topo.threads_per_core - 1) / topo.threads_per_core;
-            if (cores < static_cast<size_t>(cores_needed)) continue;
+            CPU_AND(&usable, &g.primary, &saved);
+            if (CPU_COUNT(&usable) < cores_needed) {
+                CPU_AND(&usable, &g.cpus, &saved);
+                const size_t cores = (static_cast<size_t>(CPU_COUNT(&usable)) + topo.threads_per_core - 1) / topo.threads_per_core;
+                if (cores < static_cast<size_t>(cores_needed)) continue;
+            }
             const std::string path = "/dev/shm/dark_amd.l3." + std::to_string(g.id) + ".lock";
             const int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
             if (fd >= 0) {
