@@ -73,3 +73,37 @@ def test_fullsize_properties(workload):
             ctx.dev_block_decode("dark", stream, n, d_out)
             assert torch.equal(d_out, d_in)
         print(workload, "rounds", st["rounds"], "sort passes", st["sort_passes"], "sa ms", round(st["ms_sa"], 2))
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("DK_TEST_MAXSIZE"), reason="set DK_TEST_MAXSIZE=1: needs ~230 GB of HBM and a few minutes")
+def test_largest_block_the_index_type_allows():
+    """n = 2^31 - 2 (the largest block u32 ranks + h can carry): ACGT with planted long repeats, so that the short-prefix path, the late
+    rank array and doubling rounds all run at full size."""
+    rng = np.random.default_rng(9)
+    n = (1 << 31) - 2
+    block = datagen.acgt(n, 11)
+    seg = block[12345:12345 + 300_000].copy()
+    for off in (1 << 30, (1 << 31) - 400_000, 777_777_777):
+        block[off:off + len(seg)] = seg
+    d_in = torch.from_numpy(block).cuda()
+    with dark_amd.Context(n) as ctx:
+        d_sa = torch.empty(n, dtype=torch.int32, device="cuda")
+        ctx.dev_suffix_array(d_in, n, d_sa)
+        st = ctx.stats()
+        total = 0
+        for lo in range(0, n, 1 << 28):  # checksum of a permutation of 0..n-1, in slices (keeps the int64 copy small)
+            total += int((d_sa[lo:lo + (1 << 28)].to(torch.int64) & 0xFFFFFFFF).sum().item())
+        assert total == n * (n - 1) // 2
+        pos = rng.integers(0, n - 1, size=1500)
+        a = (d_sa[torch.from_numpy(pos).cuda()].to(torch.int64) & 0xFFFFFFFF).cpu().numpy()
+        b = (d_sa[torch.from_numpy(pos + 1).cuda()].to(torch.int64) & 0xFFFFFFFF).cpu().numpy()
+        for x, y in zip(a, b):
+            lx, ly = block[x:x + 400_000].tobytes(), block[y:y + 400_000].tobytes()
+            assert lx < ly or (lx == ly and x > y), (x, y)
+        del d_sa
+        d_bwt = torch.empty(n, dtype=torch.uint8, device="cuda")
+        origin = ctx.dev_bwt_forward(d_in, n, d_bwt)
+        d_back = torch.empty(n, dtype=torch.uint8, device="cuda")
+        ctx.dev_bwt_inverse(d_bwt, n, origin, d_back)
+        assert torch.equal(d_back, d_in)
+        print("n = 2^31 - 2: rounds", st["rounds"], "sort passes", st["sort_passes"], "sa ms", round(st["ms_sa"], 2))
