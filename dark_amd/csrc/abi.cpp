@@ -64,13 +64,7 @@ int forward_to_stream(dk_ctx *ctx, const uint8_t *d_text, size_t n, bool want_ct
         const size_t mark = ctx->ws_mark();
         uint32_t *d_sa = ctx->ws_alloc<uint32_t>(n);
         if (!d_sa) return DK_E_NOMEM;
-        Timer t;
-        DK_TRY(suffix_array_device(ctx, d_text, n, d_sa));
-        DK_HIP(ctx, hipStreamSynchronize(st));
-        ctx->stats.ms_sa = t.ms();
-        Timer t2;
-        DK_TRY(bwt_gather_device(ctx, d_text, d_sa, n, d_bwt, &fr->origin));
-        ctx->stats.ms_bwt = t2.ms();
+        DK_TRY(bwt_forward_device(ctx, d_text, n, d_sa, d_bwt, &fr->origin));  // sets stats.ms_sa / ms_bwt
         ctx->ws_release(mark);
     }
     Timer t3;
@@ -222,12 +216,7 @@ int dk_dev_bwt_forward(dk_ctx *ctx, const uint8_t *d_in, size_t n, uint8_t *d_bw
     Timer t;
     uint32_t *d_sa = ctx->ws_alloc<uint32_t>(n);
     if (!d_sa) return DK_E_NOMEM;
-    DK_TRY(suffix_array_device(ctx, d_in, n, d_sa));
-    DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->stats.ms_sa = t.ms();
-    Timer t2;
-    DK_TRY(bwt_gather_device(ctx, d_in, d_sa, n, d_bwt_out, origin));
-    ctx->stats.ms_bwt = t2.ms();
+    DK_TRY(bwt_forward_device(ctx, d_in, n, d_sa, d_bwt_out, origin));
     ctx->stats.ms_total = t.ms();
     return DK_OK;
 }
@@ -485,8 +474,7 @@ int dk_bwt_forward(dk_ctx *ctx, const uint8_t *in, size_t n, uint8_t *bwt_out, u
     uint32_t *d_sa = ctx->ws_alloc<uint32_t>(n);
     if (!d_text || !d_bwt || !d_sa) return DK_E_NOMEM;
     DK_HIP(ctx, hipMemcpyAsync(d_text, in, n, hipMemcpyHostToDevice, ctx->stream));
-    DK_TRY(suffix_array_device(ctx, d_text, n, d_sa));
-    DK_TRY(bwt_gather_device(ctx, d_text, d_sa, n, d_bwt, origin));
+    DK_TRY(bwt_forward_device(ctx, d_text, n, d_sa, d_bwt, origin));
     DK_HIP(ctx, hipMemcpyAsync(bwt_out, d_bwt, n, hipMemcpyDeviceToHost, ctx->stream));
     DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stats.ms_total = t.ms();

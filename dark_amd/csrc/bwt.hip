@@ -278,6 +278,29 @@ int bwt_gather_device(dk_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, 
     return DK_OK;
 }
 
+// suffix sort + BWT: the gather is skipped when the sort already wrote L (suffix_array_device, short-prefix path)
+int bwt_forward_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_sa, uint8_t *d_bwt, uint32_t *origin) {
+    hipStream_t st = ctx->stream;
+    uint32_t *d_origin = ctx->d_mail + 8;
+    DK_HIP(ctx, hipMemsetAsync(d_origin, 0xFF, sizeof(uint32_t), st));
+    bool written = false;
+    Timer t;
+    DK_TRY(suffix_array_device(ctx, d_text, n, d_sa, d_bwt, d_origin, &written));
+    DK_HIP(ctx, hipStreamSynchronize(st));
+    ctx->stats.ms_sa = t.ms();
+    Timer t2;
+    if (!written) {
+        DK_TRY(bwt_gather_device(ctx, d_text, d_sa, n, d_bwt, origin));
+    } else {
+        DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 8, d_origin, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        DK_HIP(ctx, hipStreamSynchronize(st));
+        *origin = ctx->h_mail[8];
+        if (*origin >= n) return ctx->fail(DK_E_INTERNAL, "bwt_forward: no suffix 0 in the suffix array");
+    }
+    ctx->stats.ms_bwt = t2.ms();
+    return DK_OK;
+}
+
 int bwt_inverse_device(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t origin, uint8_t *d_out) {
     if (n == 0 || n > 0xFFFFFFF0ull || origin >= n) return ctx->fail(DK_E_ARG, "bwt_inverse: bad n / origin");
     hipStream_t st = ctx->stream;

@@ -127,7 +127,11 @@ int sort_check_error(dk_ctx *ctx);
 int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, size_t count, size_t limit, uint64_t *scratch,
                          uint32_t *dst);
 // suffix_array.hip: d_sa_out may alias nothing in the workspace; d_text is caller or ctx owned
-int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_sa_out);
+// d_bwt / d_origin / bwt_written (all three or none): when the sort finds the BWT on its way (short-prefix path) it writes L and the
+// origin word and sets *bwt_written; otherwise the caller gathers (bwt_forward_device does both)
+int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_sa_out, uint8_t *d_bwt = nullptr,
+                        uint32_t *d_origin = nullptr, bool *bwt_written = nullptr);
+int bwt_forward_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_sa, uint8_t *d_bwt, uint32_t *origin);
 // bwt.hip
 int bwt_gather_device(dk_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, size_t n, uint8_t *d_bwt, uint32_t *origin);
 int bwt_inverse_device(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t origin, uint8_t *d_out);

@@ -12,6 +12,7 @@
 // Only members of unresolved groups are ever sorted again (Larsson-Sadakane style filtering).
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "context.hpp"
@@ -43,14 +44,20 @@ constexpr int PK_G = 8;
 constexpr int PK_TILE = PK_BLOCK * PK_G;
 constexpr int PK_AHEAD = 64 + 8;  // spk <= 64
 
+// with_prev (short-prefix path, spk * bits <= 56): the key is shifted up by 8 and its low byte carries the code of the symbol in FRONT
+// of the suffix (T[n-1] for suffix 0).  The sort leaves those bits alone; a suffix that is alone in its group after the initial sort
+// then brings its BWT symbol along and needs no gather (k_rerank_apply<true>).
 __global__ __launch_bounds__(PK_BLOCK) void k_pack_keys(const uint8_t *__restrict__ t, size_t n, const uint8_t *__restrict__ code,
-                                                         int bits, int spk, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx) {
+                                                         int bits, int spk, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx,
+                                                         int with_prev) {
     __shared__ uint8_t s_code[256];
     __shared__ __attribute__((aligned(16))) uint8_t s_c[PK_TILE + PK_AHEAD + 16];
+    __shared__ uint8_t s_before;  // code of the symbol in front of the tile's first position
     const int tid = threadIdx.x;
     s_code[tid] = code[tid];
     __syncthreads();
     const size_t b0 = static_cast<size_t>(blockIdx.x) * PK_TILE;
+    if (tid == 0) s_before = s_code[t[b0 ? b0 - 1 : n - 1]];
     const bool aligned = (reinterpret_cast<uintptr_t>(t) & 15) == 0;
     for (int o = tid * 16; o < PK_TILE + PK_AHEAD; o += PK_BLOCK * 16) {
         const size_t p = b0 + o;
@@ -78,6 +85,10 @@ __global__ __launch_bounds__(PK_BLOCK) void k_pack_keys(const uint8_t *__restric
     for (int g = 1; g < PK_G; ++g) {
         key = ((key << bits) | s_c[base + spk + g - 1]) & mask;
         out[g] = key;
+    }
+    if (with_prev) {
+#pragma unroll
+        for (int g = 0; g < PK_G; ++g) out[g] = (out[g] << 8) | (base + g ? s_c[base + g - 1] : s_before);
     }
     if (i0 + PK_G <= n) {
         uint4 *kp = reinterpret_cast<uint4 *>(keys + i0);
@@ -162,6 +173,16 @@ __global__ __launch_bounds__(256) void k_rank_active(const uint32_t *__restrict_
     if (a < count) rank[act_idx[a]] = act_pos[gstart[act_gid[a]]];
 }
 
+// BWT symbols of the positions listed (the suffixes that were not final after the initial sort of the short-prefix path)
+__global__ __launch_bounds__(256) void k_bwt_gather_list(const uint8_t *__restrict__ t, const uint32_t *__restrict__ sa, size_t n,
+                                                          const uint32_t *__restrict__ list, size_t count, uint8_t *__restrict__ bwt,
+                                                          uint32_t *__restrict__ origin) {
+    const size_t a = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (a >= count) return;
+    const uint32_t p = list[a], suffix = sa[p];
+    if (suffix == 0) { bwt[p] = t[n - 1]; *origin = p; } else { bwt[p] = t[suffix - 1]; }
+}
+
 // ---- rerank: three kernels sharing the per-slot flag logic ------------------------------------------------------
 struct RerankAgg { uint32_t surv, heads, last_head, pad; };
 
@@ -181,12 +202,16 @@ __device__ __forceinline__ uint32_t slot_flag_bits(uint64_t prev, uint64_t cur, 
 }
 
 // stage keys[b0-1 .. b0+RR_TILE] into s_key[0 .. RR_TILE+1] (coalesced), then the flag bytes of the tile into s_flag
+// cmp_shift: low bits of the keys that take no part in the comparison (the previous-symbol byte of the short-prefix path); they are
+// parked in s_low (one byte per slot, s_low[o] belongs to slot b0 + o) when that is given.
 __device__ __forceinline__ void stage_flags(const uint64_t *__restrict__ keys, size_t count, size_t b0, int gshift,
-                                            uint64_t *s_key, uint8_t *s_flag) {
+                                            uint64_t *s_key, uint8_t *s_flag, int cmp_shift = 0, uint8_t *s_low = nullptr) {
     const int tid = threadIdx.x;
     for (int o = tid; o < RR_TILE + 2; o += RR_BLOCK) {
         const size_t a = b0 + o;  // slot a - 1
-        s_key[o] = (a >= 1 && a - 1 < count) ? keys[a - 1] : 0;
+        const uint64_t k = (a >= 1 && a - 1 < count) ? keys[a - 1] : 0;
+        s_key[o] = k >> cmp_shift;
+        if (s_low && o >= 1 && o <= RR_TILE) s_low[o - 1] = static_cast<uint8_t>(k);
     }
     __syncthreads();
 #pragma unroll
@@ -211,12 +236,12 @@ __device__ __forceinline__ void thread_summary(uint64_t fl, size_t a0, uint32_t 
 }
 
 __global__ __launch_bounds__(RR_BLOCK) void k_rerank_reduce(const uint64_t *__restrict__ keys, size_t count, int gshift,
-                                                             RerankAgg *__restrict__ agg) {
+                                                             RerankAgg *__restrict__ agg, int cmp_shift) {
     __shared__ uint64_t s_key[RR_TILE + 2];
     __shared__ __attribute__((aligned(8))) uint8_t s_flag[RR_TILE];
     __shared__ uint32_t s_red[3][RR_WAVES];
     const size_t b0 = static_cast<size_t>(blockIdx.x) * RR_TILE;
-    stage_flags(keys, count, b0, gshift, s_key, s_flag);
+    stage_flags(keys, count, b0, gshift, s_key, s_flag, cmp_shift);
     const size_t a0 = b0 + static_cast<size_t>(threadIdx.x) * RR_IPT;
     uint32_t ns, nh, lh;
     thread_summary(*reinterpret_cast<const uint64_t *>(s_flag + threadIdx.x * RR_IPT), a0, ns, nh, lh);
@@ -266,6 +291,10 @@ __global__ __launch_bounds__(1024) void k_rerank_scan(RerankAgg *__restrict__ ag
     if (tid == 0) { mail[0] = tot_s; mail[1] = tot_h; gstart[tot_h] = tot_s; }  // sentinel: one past the last group
 }
 
+// Short-prefix path, first rerank: the keys' low cmp_shift bits are not compared; when bwt is given they hold the code of the symbol in
+// front of the suffix, and every suffix that is final writes its BWT symbol (inv_code: code -> byte) and, for suffix 0, the origin.
+struct FirstBwt { int cmp_shift; uint8_t *bwt; const uint8_t *inv_code; uint32_t *origin; };
+
 // pos_in == nullptr means slot a sits at SA position a (first rerank, straight after the initial sort).
 // All tile inputs arrive through LDS with lane-contiguous loads; the compacted outputs leave through LDS the same way.
 // FIRST = (pos_in == nullptr): no position array to stage, 8 KiB of LDS less -> more workgroups per CU for the largest launch
@@ -275,11 +304,13 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
                                                             const RerankAgg *__restrict__ agg, uint32_t *__restrict__ rank,
                                                             uint32_t *__restrict__ sa, uint32_t *__restrict__ out_idx,
                                                             uint32_t *__restrict__ out_pos, uint32_t *__restrict__ out_gid,
-                                                            uint32_t *__restrict__ gstart, uint32_t *__restrict__ headpos_out) {
+                                                            uint32_t *__restrict__ gstart, uint32_t *__restrict__ headpos_out,
+                                                            FirstBwt fb) {
     __shared__ uint64_t s_key[RR_TILE + 2];                       // later reused: compacted idx | pos
     __shared__ __attribute__((aligned(16))) uint32_t s_idx[RR_TILE];
     __shared__ __attribute__((aligned(16))) uint32_t s_pos[FIRST ? 4 : RR_TILE];
     __shared__ __attribute__((aligned(8))) uint8_t s_flag[RR_TILE];
+    __shared__ __attribute__((aligned(8))) uint8_t s_low[FIRST ? RR_TILE : 8];  // FIRST + fb.bwt: previous-symbol codes of the tile
     __shared__ uint32_t s_tmp[RR_WAVES + 1];
     const int tid = threadIdx.x;
     const size_t b0 = static_cast<size_t>(blockIdx.x) * RR_TILE;
@@ -292,9 +323,28 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
             if (!FIRST) s_pos[o] = pos_in[a];
         }
     }
-    stage_flags(keys, count, b0, gshift, s_key, s_flag);  // ends with a barrier: s_idx / s_pos are visible, s_key is free
+    // ends with a barrier: s_idx / s_pos (/ s_low) are visible, s_key is free
+    stage_flags(keys, count, b0, gshift, s_key, s_flag, FIRST ? fb.cmp_shift : 0, (FIRST && fb.bwt) ? s_low : nullptr);
     const size_t a0 = b0 + static_cast<size_t>(tid) * RR_IPT;
     const uint64_t fl = *reinterpret_cast<const uint64_t *>(s_flag + tid * RR_IPT);
+    if (FIRST && fb.bwt && a0 < count) {
+        // singletons of the short-prefix path are final AND carry their BWT symbol: eight of them in a row leave as one 8-byte store
+        const uint64_t low8 = *reinterpret_cast<const uint64_t *>(s_low + tid * RR_IPT);
+        uint64_t sym8 = 0;
+        bool all_final = a0 + RR_IPT <= count;
+#pragma unroll
+        for (int j = 0; j < RR_IPT; ++j) {
+            sym8 |= static_cast<uint64_t>(fb.inv_code[(low8 >> (8 * j)) & 0xFFu]) << (8 * j);
+            all_final = all_final && !((fl >> (8 * j)) & F_SURV);
+        }
+        if (all_final && ((reinterpret_cast<uintptr_t>(fb.bwt) + a0) & 7) == 0) {
+            *reinterpret_cast<uint64_t *>(fb.bwt + a0) = sym8;
+        } else {
+#pragma unroll
+            for (int j = 0; j < RR_IPT; ++j)
+                if (a0 + j < count && !((fl >> (8 * j)) & F_SURV)) fb.bwt[a0 + j] = static_cast<uint8_t>(sym8 >> (8 * j));
+        }
+    }
     uint32_t ns, nh, lh;
     thread_summary(fl, a0, ns, nh, lh);
     const RerankAgg base = agg[blockIdx.x];
@@ -335,6 +385,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
         else if (rank && !(el & 1u)) rank[suffix] = head_pos;  // members of a group that kept its head keep their rank: no scatter
         if (!(f & F_SURV)) {
             sa[my_pos[j]] = suffix;  // the group is a singleton: this suffix is in its final place
+            if (FIRST && fb.bwt && suffix == 0) *fb.origin = my_pos[j];
         } else {
             if (f & F_HEAD) { gstart[eh] = base.surv + es; ++eh; }  // first slot of the surviving group in the new active list
             s_oidx[es] = suffix;
@@ -356,7 +407,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
 // rank array, so the apply phase only writes SA.
 int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_t *pos_in, size_t count, int gshift, uint32_t *rank,
            uint32_t *sa, uint32_t *out_idx, uint32_t *out_pos, uint32_t *out_gid, uint32_t *gstart, uint32_t *headpos_out = nullptr,
-           bool probe_active = false, bool *ranks_written = nullptr) {
+           bool probe_active = false, bool *ranks_written = nullptr, FirstBwt fb = FirstBwt{0, nullptr, nullptr, nullptr}) {
     const size_t ntiles = div_up(count, RR_TILE);
     const size_t mark = ctx->ws_mark();
     RerankAgg *agg = ctx->ws_alloc<RerankAgg>(ntiles);
@@ -364,7 +415,7 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
     hipStream_t st = ctx->stream;
     {
         LaunchScope ls(ctx, K_RERANK_REDUCE, 8.0 * count);
-        k_rerank_reduce<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, count, gshift, agg);
+        k_rerank_reduce<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, count, gshift, agg, pos_in ? 0 : fb.cmp_shift);
     }
     {
         LaunchScope ls(ctx, K_RERANK_SCAN, 32.0 * ntiles);
@@ -383,9 +434,9 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
     {
         LaunchScope ls(ctx, K_RERANK_APPLY, 8.0 * count + 4.0 * count + 4.0 * count + 12.0 * count);
         if (pos_in)
-            k_rerank_apply<false><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gshift, agg, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out);
+            k_rerank_apply<false><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gshift, agg, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out, fb);
         else
-            k_rerank_apply<true><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gshift, agg, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out);
+            k_rerank_apply<true><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gshift, agg, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out, fb);
     }
     DK_HIP(ctx, hipGetLastError());
     ctx->ws_release(mark);
@@ -583,7 +634,8 @@ int classify_and_read(dk_ctx *ctx, size_t max_groups, uint32_t *gstart, uint32_t
 
 }  // namespace
 
-int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_sa) {
+int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_sa, uint8_t *d_bwt, uint32_t *d_origin, bool *bwt_written) {
+    if (bwt_written) *bwt_written = false;
     if (n == 0 || n > 0x7FFFFFFEull) return ctx->fail(DK_E_ARG, "suffix_array: n out of range");
     hipStream_t st = ctx->stream;
     ctx->stats.rounds = 0;
@@ -667,14 +719,24 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
         }
     }
     const bool short_prefix = spk_sort < spk;
+    // BWT on the way (callers that want L, short-prefix path, room for one more byte in the key): see k_pack_keys / FirstBwt
+    const bool carry_bwt = short_prefix && d_bwt && d_origin && bwt_written && bits * spk_sort <= 56;
+    uint8_t *d_inv = reinterpret_cast<uint8_t *>(ctx->d_mail + 576);
+    if (carry_bwt) {
+        uint8_t inv[256] = {0};
+        for (int sym = 255; sym >= 0; --sym)
+            if (ctx->h_mail[16 + sym]) inv[code[sym]] = static_cast<uint8_t>(sym);
+        std::memcpy(ctx->h_mail + 576, inv, 256);
+        DK_HIP(ctx, hipMemcpyAsync(d_inv, ctx->h_mail + 576, 256, hipMemcpyHostToDevice, st));
+    }
 
     // 3. initial keys and sort
     {
         LaunchScope ls(ctx, K_PACK_KEYS, 1.0 * n + 12.0 * n);
-        k_pack_keys<<<dim3(div_up(n, PK_TILE)), dim3(PK_BLOCK), 0, st>>>(d_text, n, d_code, bits, spk_sort, keys, vals);
+        k_pack_keys<<<dim3(div_up(n, PK_TILE)), dim3(PK_BLOCK), 0, st>>>(d_text, n, d_code, bits, spk_sort, keys, vals, carry_bwt ? 1 : 0);
     }
     DK_HIP(ctx, hipGetLastError());
-    DK_TRY(sort_pairs(ctx, keys, keys_alt, vals, vals_alt, n, 0, bits * spk_sort));
+    DK_TRY(sort_pairs(ctx, keys, keys_alt, vals, vals_alt, n, carry_bwt ? 8 : 0, bits * spk_sort + (carry_bwt ? 8 : 0)));
 
     // 4. first rerank (slots are SA positions)
     size_t active = 0, groups = 0, nbig = 0;
@@ -682,7 +744,8 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     static const bool bucketed = [] { const char *e = getenv("DK_BUCKETED"); return !(e && e[0] == '0'); }();
     if (short_prefix) {
         // few suffixes are expected to survive and they are finished from the text: no rank array unless that fails (step 5b)
-        DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, nullptr, d_sa, vals_alt, pos, gid, gstart));
+        const FirstBwt fb{carry_bwt ? 8 : 0, carry_bwt ? d_bwt : nullptr, d_inv, d_origin};
+        DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, nullptr, d_sa, vals_alt, pos, gid, gstart, nullptr, false, nullptr, fb));
         have_ranks = false;
     } else if (bucketed && n >= (1u << 22)) {
         // rank[suffix] = head position for all n suffixes: too random for plain stores (every 4-byte store is a 64-byte line
@@ -695,6 +758,14 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     }
     DK_TRY(classify_and_read(ctx, n / 2, gstart, bigstart, &active, &groups, &nbig));
     std::swap(vals, vals_alt);  // vals = suffix indices of the active list
+    // the SA positions that are still open: their BWT symbols are gathered at the very end (carry_bwt)
+    uint32_t *open_pos = nullptr;
+    const size_t open_count = active;
+    if (carry_bwt && active > 0) {
+        open_pos = ctx->ws_alloc<uint32_t>(active);
+        if (!open_pos) return DK_E_NOMEM;
+        DK_HIP(ctx, hipMemcpyAsync(open_pos, pos, active * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    }
 
     uint64_t h = static_cast<uint64_t>(spk_sort);
     if (trace)
@@ -772,6 +843,14 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
         const uint32_t h_eff = static_cast<uint32_t>(std::min<uint64_t>(h, n));
         DK_TRY(run_round(static_cast<int>(ceil_log2_u64(static_cast<uint64_t>(n) + h_eff)), 0));
         h *= 2;
+    }
+    if (carry_bwt) {
+        if (open_count > 0) {
+            LaunchScope ls(ctx, K_BWT_GATHER, 10.0 * open_count);
+            k_bwt_gather_list<<<dim3(div_up(open_count, 256)), dim3(256), 0, st>>>(d_text, d_sa, n, open_pos, open_count, d_bwt, d_origin);
+        }
+        DK_HIP(ctx, hipGetLastError());
+        *bwt_written = true;
     }
     ctx->ws_release(mark);
     DK_TRY(sort_check_error(ctx));

@@ -105,6 +105,10 @@ with dark_amd.Context(6 << 20) as ctx:
         t = np.ascontiguousarray(t)
         want = orc.sa_sais(t) if len(t) > 1 else np.zeros(1, np.uint32)
         assert (ctx.suffix_array(t) == want).all(), name
+        if len(t) > 1:  # the BWT rides along with the short-prefix sort (previous symbol in the keys' low byte)
+            bwt, origin = ctx.bwt_forward(t)
+            wb, wo = orc.bwt_forward(t)
+            assert origin == wo and (np.frombuffer(bwt, np.uint8) == np.frombuffer(wb, np.uint8)).all(), name
 print("ok")
 """
 
