@@ -1,0 +1,19 @@
+"""A short run of the randomized parity campaign (tools/fuzz_gpu.py): suffix array, BWT + origin, DC arrays and whole-block streams
+against the oracle on inputs built to cross the thresholds of the suffix sort and of the distance coder."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("prefix_mode", ["1", "2"])
+def test_randomized_campaign(prefix_mode):
+    env = dict(os.environ, DK_PREFIX=prefix_mode)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), "10", "5"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]
