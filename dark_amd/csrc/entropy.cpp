@@ -1041,14 +1041,48 @@ __attribute__((noinline)) int code_uniform(URing &ring, uint8_t *out, size_t cap
         const uint32_t count = v & ~URing::kEnd;
         const UEvent *ev = ring.slot(slot);
         if (!err && len + 4 * static_cast<size_t>(count) + 12 <= cap) {  // room for the worst case of this batch: unchecked stores
+            // The coder's state as (low, span = hi - low): the new span is r * (to - from) shifted like the borders -- computed beside the
+            // two border products instead of by a subtraction after the shift -- so the chain from one decision to the next is
+            //     span -> r (mulx) -> low + r * from (imul, add) -> xor with the upper border -> clz & 24 -> shifted span.
             uint8_t *p = out + len;
+            uint32_t low = rs.low, span = rs.hi - rs.low;
             for (uint32_t k = 0; k < count; ++k) {
-                const uint32_t span = rs.hi - rs.low;
                 const uint32_t r = static_cast<uint32_t>((static_cast<unsigned __int128>(span) * ev[k].inv) >> 64);
-                const int nb = r ? rs.narrow(r, ev[k].from, ev[k].to, p) : -1;
-                if (nb < 0) { err = DK_E_INTERNAL; break; }
-                p += nb;
+                uint32_t lo = low + r * ev[k].from, h = low + r * ev[k].to, s = r * (ev[k].to - ev[k].from);
+                const uint32_t x = lo ^ h;
+                if (__builtin_expect(r == 0 || x == 0, 0)) { err = DK_E_INTERNAL; break; }
+                const unsigned sh = static_cast<unsigned>(__builtin_clz(x)) & 24u;
+                const uint32_t be = __builtin_bswap32(lo);
+                std::memcpy(p, &be, 4);
+                p += sh >> 3;
+                lo <<= sh;
+                s <<= sh;
+                if (__builtin_expect(s <= kRangeThreshold, 0)) {  // threshold cut: the reference's loop from its second round on
+                    h = lo + s;
+                    int shifted = static_cast<int>(sh >> 3);
+                    for (;;) {
+                        const uint32_t lim = h & kTopMask;
+                        if (h - lim >= lim - lo) lo = lim; else h = lim - 1;
+                        const uint32_t x2 = lo ^ h;
+                        if (x2 == 0) { err = DK_E_INTERNAL; break; }
+                        const unsigned sh2 = static_cast<unsigned>(__builtin_clz(x2)) & 24u;
+                        const uint32_t be2 = __builtin_bswap32(lo);
+                        std::memcpy(p, &be2, 4);
+                        p += sh2 >> 3;
+                        shifted += static_cast<int>(sh2 >> 3);
+                        if (shifted > 4) { err = DK_E_INTERNAL; break; }
+                        lo <<= sh2;
+                        h <<= sh2;
+                        if (h - lo > kRangeThreshold) break;
+                    }
+                    if (err) break;
+                    s = h - lo;
+                }
+                low = lo;
+                span = s;
             }
+            rs.low = low;
+            rs.hi = low + span;
             len = static_cast<size_t>(p - out);
         } else if (!err) {  // close to the end of the caller's buffer: every event through a scratch word, exact check
             for (uint32_t k = 0; k < count; ++k) {
