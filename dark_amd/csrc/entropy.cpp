@@ -896,7 +896,7 @@ public:
     static constexpr uint32_t kBatch = 2048;  // events per batch (32 KiB)
     static constexpr int kSlots = 16;
     static constexpr uint32_t kEnd = 0x80000000u;
-    URing() : buf_(new UEvent[static_cast<size_t>(kSlots) * kBatch]) {
+    URing() : buf_(new UEvent[static_cast<size_t>(kSlots) * kBatch + 4]) {  // + 4: the merger copies four events at a time
         for (auto &c : ready_) c.store(0, std::memory_order_relaxed);
     }
     UEvent *slot(int i) { return buf_.get() + static_cast<size_t>(i) * kBatch; }
@@ -935,6 +935,12 @@ public:
         cur_[fill_++] = ev;
         return true;
     }
+    // bulk interface (merger): at least `want` (<= 4) free places at tail(), then advance(count <= want)
+    inline UEvent *tail(uint32_t want) {
+        if (fill_ + want > URing::kBatch) flush();
+        return cur_ + fill_;
+    }
+    inline void advance(uint32_t count) { fill_ += count; }
     inline bool put(uint32_t total, uint32_t from, uint32_t to) {
         if (!(from < to && to <= total && total < 32768u && total >= 2u)) return fail(DK_E_INTERNAL);
         return raw(UEvent{total < (1u << 14) ? inv_[total] : reciprocal64(total), from, to});
@@ -973,6 +979,11 @@ public:
         if (pos_ == count_ && !refill()) return nullptr;
         return cur_ + pos_++;
     }
+    // bulk interface (merger): events left in the current batch (0: ask refill_batch()), a pointer to them, skip(count)
+    inline uint32_t available() const { return count_ - pos_; }
+    inline const UEvent *head() const { return cur_ + pos_; }
+    inline void skip(uint32_t count) { pos_ += count; }
+    inline bool refill_batch() { return refill(); }
     void drain() {
         while (!last_) { ring_.release(slot_); slot_ = (slot_ + 1) % URing::kSlots; next_batch(); }
         ring_.release(slot_);
@@ -1013,20 +1024,32 @@ struct DarkMantissaSide {
 struct DarkMergeSide {  // the order of dark.rs:180-232: table decision, unary extension, mantissa bits
     UReader &exponent;
     UReader &mantissa;
-    bool encode(uint32_t dist, uint8_t, USink &e) {
-        if (dist >= 0x7FFFFFFFu) return false;
-        const unsigned log = bit_length(dist + 1);
-        for (unsigned k = 1 + DarkModel::exponent_bits(dist); k; --k) {
-            const UEvent *ev = exponent.next();
-            if (!ev) return false;
-            e.raw(*ev);
-        }
-        for (unsigned k = log - 1; k; --k) {
-            const UEvent *ev = mantissa.next();
-            if (!ev) return false;
-            e.raw(*ev);
+    // `count` events from one ring to the other, four (64 bytes, two vector copies) at a time whenever both sides have four places:
+    // what is copied beyond `count` is overwritten by the next copy, and no loop exit depends on the small counts of the usual case
+    static inline bool move(UReader &from, USink &to, unsigned count) {
+        while (count) {
+            uint32_t have = from.available();
+            if (have == 0) {
+                if (!from.refill_batch()) return false;
+                have = from.available();
+            }
+            if (have >= 4) {
+                const unsigned c = count < 4 ? count : 4;
+                std::memcpy(static_cast<void *>(to.tail(4)), from.head(), 4 * sizeof(UEvent));
+                to.advance(c);
+                from.skip(c);
+                count -= c;
+            } else {  // end of an input batch: one by one
+                to.raw(*from.head());
+                from.skip(1);
+                count -= 1;
+            }
         }
         return true;
+    }
+    bool encode(uint32_t dist, uint8_t, USink &e) {
+        if (dist >= 0x7FFFFFFFu) return false;
+        return move(exponent, e, 1 + DarkModel::exponent_bits(dist)) && move(mantissa, e, bit_length(dist + 1) - 1);
     }
 };
 
