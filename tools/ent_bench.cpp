@@ -1,3 +1,4 @@
+// host entropy stage alone on the sample written by tools/make_dc_sample.py: six encodes (DK_ENTROPY_THREADS selects the form), one decode
 #include "../dark_amd/csrc/entropy.hpp"
 #include <chrono>
 #include <cstdio>

@@ -1,5 +1,7 @@
+"""suffix sort on pathological inputs (long runs, periodic text, Fibonacci words ...): correctness against the oracle and timings"""
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dark_amd
 from oracle import orc
 cases = {
