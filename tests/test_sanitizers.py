@@ -1,0 +1,27 @@
+"""Host entropy stage under AddressSanitizer + UndefinedBehaviorSanitizer (CPU build; GPU sanitizers are not available on the pool):
+tools/ent_fuzz.cpp round-trips every model and decodes thousands of mutated / truncated streams and random distance arrays."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs the ROCm clang++")
+def test_host_decoders_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "ent_fuzz")
+    cmd = [CLANG, "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17", "-march=x86-64-v3",
+           "-I" + os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "tools", "ent_fuzz.cpp"),
+           os.path.join(ROOT, "dark_amd", "csrc", "entropy.cpp"), "-lpthread"]
+    build = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if build.returncode != 0 and "sanitizer" in (build.stderr or "").lower() and "not found" in build.stderr.lower():
+        pytest.skip("sanitizer runtime not installed")
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([exe, "250"], capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0 and "failures 0" in run.stdout, run.stdout[-2000:] + run.stderr[-4000:]
+    assert "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr, run.stderr[-4000:]
+    shutil.rmtree(tmp_path, ignore_errors=True)
