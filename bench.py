@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=125_000_000,
                     help="bytes of the block the CPU oracle is timed on (default: the whole block up to 125 MB, about 10 s of one core)")
     ap.add_argument("--no-decode", action="store_true")
-    ap.add_argument("--pipeline-blocks", type=int, default=16,
+    ap.add_argument("--pipeline-blocks", type=int, default=15,
                     help="extra leg: this many blocks in flight on one GPU, device stages pipelined against host coding (0 = skip)")
     ap.add_argument("--pipeline-threads", type=int, default=15)
     return ap.parse_args()
@@ -185,6 +185,10 @@ def main():
     pipelined = None
     if args.pipeline_blocks > 0:
         B = max(2, min(args.pipeline_blocks, int(2.4e9 // n)))  # bound pinned staging (about 3 bytes per input byte per block)
+        # one serial coding pass per block and worker: a block count that is a multiple of the workers keeps every worker busy to the
+        # end (16 blocks on 15 workers would spend half of the time on the sixteenth)
+        if B > args.pipeline_threads:
+            B -= B % args.pipeline_threads
         outs = [np.empty(len(stream) + len(stream) // 8 + 65536, dtype=np.uint8) for _ in range(B)]
         try:
             ctx.dev_batch_encode(args.model, [d_in] * 2, [n] * 2, args.pipeline_threads, outs[:2])  # warm the staging slots
