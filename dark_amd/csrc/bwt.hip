@@ -19,28 +19,34 @@ namespace dk {
 namespace {
 
 // ---- forward ------------------------------------------------------------------------------------------------------
+constexpr int BG_PER_THREAD = 16;  // gathers in flight per thread (all addresses first, then all symbols): the kernel is latency-bound
 __global__ __launch_bounds__(256) void k_bwt_gather(const uint8_t *__restrict__ t, const uint32_t *__restrict__ sa, size_t n,
                                                      uint8_t *__restrict__ bwt, uint32_t *__restrict__ origin) {
-    // 4 outputs per thread so that the byte stores leave as one dword
-    const size_t j0 = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 4;
+    const size_t j0 = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * BG_PER_THREAD;
     if (j0 >= n) return;
-    uint32_t packed = 0;
-    const int cnt = n - j0 < 4 ? static_cast<int>(n - j0) : 4;
-    for (int k = 0; k < cnt; ++k) {
-        const uint32_t p = sa[j0 + k];
-        uint8_t c;
-        if (p == 0) {
-            c = t[n - 1];
-            *origin = static_cast<uint32_t>(j0 + k);
-        } else {
-            c = t[p - 1];
+    if (j0 + BG_PER_THREAD <= n && (reinterpret_cast<uintptr_t>(bwt) & 15) == 0 && (reinterpret_cast<uintptr_t>(sa) & 15) == 0) {
+        uint32_t p[BG_PER_THREAD];
+#pragma unroll
+        for (int q = 0; q < BG_PER_THREAD / 4; ++q) {
+            const uint4 v = reinterpret_cast<const uint4 *>(sa + j0)[q];
+            p[4 * q] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
         }
-        packed |= static_cast<uint32_t>(c) << (8 * k);
+        uint8_t c[BG_PER_THREAD];
+#pragma unroll
+        for (int k = 0; k < BG_PER_THREAD; ++k) c[k] = t[p[k] ? p[k] - 1 : n - 1];
+        uint32_t w[BG_PER_THREAD / 4];
+#pragma unroll
+        for (int q = 0; q < BG_PER_THREAD / 4; ++q)
+            w[q] = c[4 * q] | (static_cast<uint32_t>(c[4 * q + 1]) << 8) | (static_cast<uint32_t>(c[4 * q + 2]) << 16) | (static_cast<uint32_t>(c[4 * q + 3]) << 24);
+#pragma unroll
+        for (int k = 0; k < BG_PER_THREAD; ++k)
+            if (p[k] == 0) *origin = static_cast<uint32_t>(j0 + k);
+        *reinterpret_cast<uint4 *>(bwt + j0) = make_uint4(w[0], w[1], w[2], w[3]);
+        return;
     }
-    if (cnt == 4 && (reinterpret_cast<uintptr_t>(bwt) & 3) == 0) {
-        *reinterpret_cast<uint32_t *>(bwt + j0) = packed;
-    } else {
-        for (int k = 0; k < cnt; ++k) bwt[j0 + k] = static_cast<uint8_t>(packed >> (8 * k));
+    for (size_t j = j0; j < n && j < j0 + BG_PER_THREAD; ++j) {
+        const uint32_t p = sa[j];
+        if (p == 0) { bwt[j] = t[n - 1]; *origin = static_cast<uint32_t>(j); } else { bwt[j] = t[p - 1]; }
     }
 }
 
@@ -268,7 +274,7 @@ int bwt_gather_device(dk_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, 
     DK_HIP(ctx, hipMemsetAsync(d_origin, 0xFF, sizeof(uint32_t), st));
     {
         LaunchScope ls(ctx, K_BWT_GATHER, 6.0 * n);
-        k_bwt_gather<<<dim3(div_up(div_up(n, 4), 256)), dim3(256), 0, st>>>(d_text, d_sa, n, d_bwt, d_origin);
+        k_bwt_gather<<<dim3(div_up(div_up(n, BG_PER_THREAD), 256)), dim3(256), 0, st>>>(d_text, d_sa, n, d_bwt, d_origin);
     }
     DK_HIP(ctx, hipGetLastError());
     DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 8, d_origin, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
