@@ -9,6 +9,9 @@ events on the library's own stream, and the CPU oracle timed on a bounded sample
 
 Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), independent blocks, no data-path collective;
 RCCL only gathers the final bitstreams on rank 0 (inside the timed region).  Scaling is weak: one block per GPU.
+`python bench.py --gpus N` without a launcher starts the N rank processes itself (the parent never touches the GPU and only
+relays the children's output); under torchrun (WORLD_SIZE set) it is one of the ranks.  Every rank gets the same host-CPU share
+at every N: container CPU quota / GPUs of the node, so that the N=1 line is the per-rank baseline of the N=8 line.
 """
 import argparse
 import json
@@ -40,7 +43,45 @@ def parse():
     ap.add_argument("--pipeline-blocks", type=int, default=15,
                     help="extra leg: this many blocks in flight on one GPU, device stages pipelined against host coding (0 = skip)")
     ap.add_argument("--pipeline-threads", type=int, default=15)
+    ap.add_argument("--pipeline-reps", type=int, default=3, help="timed repetitions of the pipelined leg (distinct blocks per repetition)")
+    ap.add_argument("--gather", default="rccl", choices=("rccl", "host"),
+                    help="how the final bitstreams reach rank 0 inside the timed region: RCCL over xGMI (north_star) or a host-side gloo gather; "
+                         "the other one is timed beside it")
+    ap.add_argument("--node-gpus", type=int, default=0, help="GPUs of the node the per-rank CPU share is computed for (default: visible devices)")
+    ap.add_argument("--stub-exchange", action="store_true",
+                    help="CPU rehearsal of the multi-rank plumbing (launcher, process group, exchange, max-over-ranks timing) with backend gloo: "
+                         "the per-rank streams come from the product's host coder on seeded distances; no GPU is touched")
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args):
+    """--gpus N without a launcher: start N fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment, exactly what torchrun would set) and wait.  This parent has not imported torch or touched HIP and never does."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:  # a rank failed: make sure none is left waiting in a collective
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def make_block(workload, seed_offset, n_override):
@@ -58,6 +99,72 @@ def make_block(workload, seed_offset, n_override):
     return fn(n, seed + seed_offset)
 
 
+def exchange_streams(torch, dist, stream_np, world, rank, dev, group):
+    """lengths all_gather + padded gather to rank 0.  dev = a cuda device: default (nccl = RCCL) group, device buffers;
+    dev = None: `group` (gloo), host buffers."""
+    kw = {} if dev is not None else {"group": group}
+    where = dev if dev is not None else "cpu"
+    ln = torch.tensor([len(stream_np)], dtype=torch.int64, device=where)
+    lens = [torch.zeros(1, dtype=torch.int64, device=where) for _ in range(world)]
+    dist.all_gather(lens, ln, **kw)
+    lens = [int(x.item()) for x in lens]
+    mx = max(lens)
+    pad = torch.zeros(mx, dtype=torch.uint8, device=where)
+    pad[:len(stream_np)] = torch.from_numpy(stream_np).to(where)
+    if rank == 0:
+        bufs = [torch.empty(mx, dtype=torch.uint8, device=where) for _ in range(world)]
+        dist.gather(pad, bufs, dst=0, **kw)
+        return [b[:l] for b, l in zip(bufs, lens)]
+    dist.gather(pad, None, dst=0, **kw)
+    return None
+
+
+def stub_exchange(args, world, rank):
+    """CPU rehearsal of the N-rank plumbing (tests/test_dist_gloo.py): same launcher, same exchange code, backend gloo."""
+    import torch
+    import torch.distributed as dist
+    from dark_amd import model
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    def rank_input(r):
+        rng = np.random.default_rng(1000 + r)
+        m = 20000 + 777 * r
+        return (rng.integers(0, 1 << 16, size=m, dtype=np.uint32) >> rng.integers(0, 16, size=m).astype(np.uint32)), rng.integers(0, 256, size=m, dtype=np.uint8)
+
+    d, sym = rank_input(rank)
+
+    def step():
+        s = np.frombuffer(model.encode(args.model, d, sym), dtype=np.uint8).copy()  # product host coder (dk_model_encode), no oracle
+        return s, (exchange_streams(torch, dist, s, world, rank, None, None) if world > 1 else [torch.from_numpy(s.copy())])
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stream, got = step()
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        ok = len(got) == world
+        for r, g in enumerate(got):
+            dr, sr = rank_input(r)
+            ok = ok and bool((model.decode(args.model, g.numpy().tobytes(), sr) == dr).all())
+        print(json.dumps({"metric": "stub_exchange", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * float(el.item()) / args.steps, 3), "gathered_streams_decode": bool(ok),
+                          "stream_bytes": [int(len(g)) for g in got], "backend": "gloo", "data": "synthetic"}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def cpu_budget():
     """CPUs this container may use (cgroup quota; os.cpu_count() when unlimited)."""
     try:
@@ -71,29 +178,38 @@ def cpu_budget():
 
 def main():
     args = parse()
-    # Host threads: the ranks of one node share the container's CPU quota.  The single-block encoder busy-waits on up to four cores
-    # per rank; tell the library to stay within this rank's share (it reads DK_ENTROPY_THREADS once, when it is loaded).
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    share = max(1, cpu_budget() // max(1, local_world))
-    if "DK_ENTROPY_THREADS" not in os.environ and share < 4:
-        os.environ["DK_ENTROPY_THREADS"] = "2" if share >= 2 else "1"
-    args.pipeline_threads = max(1, min(args.pipeline_threads, share - 1))
-    import torch
-    import torch.distributed as dist
-    import dark_amd
-
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; pass the same N to both" % (args.gpus, world))
+    if args.stub_exchange:
+        return stub_exchange(args, world, rank)
+    import torch  # device_count() does not initialise the GPU on this image
+    # Host threads: the ranks of one node share the container's CPU quota.  Every rank gets quota / (GPUs of the node), at every N, so
+    # that an N=1 run uses exactly the per-rank resources of an N=8 run on the same node.  The single-block encoder busy-waits on up
+    # to four cores per rank; tell the library to stay within the share (it reads DK_ENTROPY_THREADS once, when it is loaded).
+    node_gpus = max(args.node_gpus or torch.cuda.device_count(), world, 1)
+    share = max(1, cpu_budget() // node_gpus)
+    if "DK_ENTROPY_THREADS" not in os.environ and share < 4:
+        os.environ["DK_ENTROPY_THREADS"] = "2" if share >= 2 else "1"
+    args.pipeline_threads = max(1, min(args.pipeline_threads, share - 1))
+    import torch.distributed as dist
+    import dark_amd
+
+    host_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        host_group = dist.new_group(backend="gloo")  # the host-side alternative for the final gather
     else:
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
     t_gen = time.time()
@@ -109,22 +225,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def gather_streams(stream_np):
-        """RCCL gathers the final bitstreams on rank 0: lengths first, then the padded payloads."""
+    def gather_streams(stream_np, how=None):
+        """The final bitstreams reach rank 0: lengths first (all_gather), then the padded payloads (gather).
+        rccl: through device buffers over xGMI (north_star); host: the stream never leaves host memory (gloo)."""
         if world == 1:
             return [stream_np]
-        ln = torch.tensor([len(stream_np)], dtype=torch.int64, device=dev)
-        lens = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(lens, ln)
-        mx = int(max(int(x.item()) for x in lens))
-        pad = torch.zeros(mx, dtype=torch.uint8, device=dev)
-        pad[:len(stream_np)] = torch.from_numpy(stream_np).to(dev)
-        if rank == 0:
-            bufs = [torch.empty(mx, dtype=torch.uint8, device=dev) for _ in range(world)]
-            dist.gather(pad, bufs, dst=0)
-            return [b[:int(l.item())] for b, l in zip(bufs, lens)]
-        dist.gather(pad, None, dst=0)
-        return None
+        return exchange_streams(torch, dist, stream_np, world, rank, dev if (how or args.gather) == "rccl" else None, host_group)
 
     def encode_step():
         s = ctx.dev_block_encode(args.model, d_in, n, out_buf)
@@ -180,8 +286,27 @@ def main():
             roundtrip_ok = "undecodable by reference format: %s" % e
             dstats = None
 
+    # the two ways the final bitstreams can reach rank 0, timed on the stream just produced (the headline used args.gather)
+    gather_ms = None
+    if world > 1:
+        gather_ms = {}
+        for how in ("rccl", "host"):
+            gather_streams(stream, how)
+            barrier()
+            tg = time.perf_counter()
+            for _ in range(3):
+                got = gather_streams(stream, how)
+            barrier()
+            dtg = torch.tensor([time.perf_counter() - tg], dtype=torch.float64, device=dev)
+            dist.all_reduce(dtg, op=dist.ReduceOp.MAX)
+            gather_ms[how] = round(1e3 * float(dtg.item()) / 3, 3)
+            if rank == 0:  # rank 0's own stream must come back intact through either route
+                gather_ms[how + "_ok"] = bool(len(got) == world and got[0].cpu().numpy().tobytes() == stream.tobytes())
+
     # pipelined leg: B independent blocks per GPU, the device path of block i+1 overlapping the host coding of earlier blocks
     # ("one block per core, pipelined against GPU work of the next block").  Reported beside the headline, never as it.
+    # Blocks are distinct: block j of repetition r is the input rotated by a different offset (same statistics, different suffix order);
+    # block 0 of every repetition is the input itself, whose stream must equal the single-block path's.
     pipelined = None
     if args.pipeline_blocks > 0:
         B = max(2, min(args.pipeline_blocks, int(2.4e9 // n)))  # bound pinned staging (about 3 bytes per input byte per block)
@@ -189,33 +314,54 @@ def main():
         # end (16 blocks on 15 workers would spend half of the time on the sixteenth)
         if B > args.pipeline_threads:
             B -= B % args.pipeline_threads
-        outs = [np.empty(len(stream) + len(stream) // 8 + 65536, dtype=np.uint8) for _ in range(B)]
+        cap = len(stream) + len(stream) // 4 + 65536
+        outs = [np.empty(cap, dtype=np.uint8) for _ in range(B)]
         try:
-            ctx.dev_batch_encode(args.model, [d_in] * 2, [n] * 2, args.pipeline_threads, outs[:2])  # warm the staging slots
-            warm = ctx.dev_batch_encode(args.model, [d_in] * B, [n] * B, args.pipeline_threads, outs)
-            barrier()
-            tp = time.perf_counter()
-            res = ctx.dev_batch_encode(args.model, [d_in] * B, [n] * B, args.pipeline_threads, outs)
-            barrier()
-            dtp = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device=dev)
-            if world > 1:
-                dist.all_reduce(dtp, op=dist.ReduceOp.MAX)
-            same = all(r.tobytes() == stream.tobytes() for r in (res[0], res[-1]))
-            pipelined = {"blocks_per_gpu": B, "host_threads": args.pipeline_threads, "MBps": round(world * B * n / float(dtp.item()) / 1e6, 1),
-                         "seconds": round(float(dtp.item()), 3), "streams_identical_to_single_block_path": bool(same)}
-            del warm
-            if not args.no_decode and roundtrip_ok is True:
-                d_outs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(B)]
+            d_blocks = [d_in] + [torch.empty_like(d_in) for _ in range(B - 1)]
+
+            def rotate(rep):
+                for j in range(1, B):
+                    off = (1 + rep * B + j) * 1_000_003 % n
+                    d_blocks[j][:n - off] = d_in[off:]
+                    d_blocks[j][n - off:] = d_in[:off]
+                torch.cuda.synchronize(dev)
+
+            rotate(0)
+            ctx.dev_batch_encode(args.model, d_blocks[:2], [n] * 2, args.pipeline_threads, outs[:2])  # warm the staging slots
+            ctx.dev_batch_encode(args.model, d_blocks, [n] * B, args.pipeline_threads, outs)
+            secs = []
+            same = True
+            for rep in range(1, args.pipeline_reps + 1):
+                rotate(rep)
                 barrier()
                 tp = time.perf_counter()
-                ctx.dev_batch_decode(args.model, res, [n] * B, d_outs, args.pipeline_threads)
+                res = ctx.dev_batch_encode(args.model, d_blocks, [n] * B, args.pipeline_threads, outs)
                 barrier()
-                dtd = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device=dev)
+                dtp = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device=dev)
                 if world > 1:
-                    dist.all_reduce(dtd, op=dist.ReduceOp.MAX)
-                pipelined["decode_MBps"] = round(world * B * n / float(dtd.item()) / 1e6, 1)
-                pipelined["decode_roundtrip_ok"] = bool(all(torch.equal(o, d_in) for o in (d_outs[0], d_outs[-1])))
+                    dist.all_reduce(dtp, op=dist.ReduceOp.MAX)
+                secs.append(float(dtp.item()))
+                same = same and res[0].tobytes() == stream.tobytes()
+            med = sorted(secs)[len(secs) // 2]
+            pipelined = {"blocks_per_gpu": B, "host_threads": args.pipeline_threads, "repetitions": len(secs), "distinct_blocks": True,
+                         "MBps": round(world * B * n / med / 1e6, 1), "seconds_median": round(med, 3),
+                         "seconds_all": [round(x, 3) for x in secs], "streams_identical_to_single_block_path": bool(same)}
+            if not args.no_decode and roundtrip_ok is True:
+                d_outs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(B)]
+                dsecs = []
+                for rep in range(max(1, args.pipeline_reps)):
+                    barrier()
+                    tp = time.perf_counter()
+                    ctx.dev_batch_decode(args.model, res, [n] * B, d_outs, args.pipeline_threads)
+                    barrier()
+                    dtd = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device=dev)
+                    if world > 1:
+                        dist.all_reduce(dtd, op=dist.ReduceOp.MAX)
+                    dsecs.append(float(dtd.item()))
+                pipelined["decode_MBps"] = round(world * B * n / sorted(dsecs)[len(dsecs) // 2] / 1e6, 1)
+                pipelined["decode_roundtrip_ok"] = bool(all(torch.equal(o, b_) for o, b_ in zip(d_outs, d_blocks)))
                 del d_outs
+            del d_blocks
         except dark_amd.DarkError as e:
             pipelined = {"error": str(e)}
         del outs
@@ -245,12 +391,17 @@ def main():
         kern = stats["kernels"]
         dom_name = max(kern, key=lambda kk: kern[kk]["ms"]) if kern else None
         roofline = None
-        pmc = None
-        try:  # HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (same command, same workload)
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_enwik8like_1e8.json")) as f:
-                pmc = json.load(f)
-        except OSError:
-            pass
+        # HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (same command, same workload; newest round)
+        pmc, pmc_path = None, None
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_*.json"))):
+            try:
+                with open(path) as f:
+                    cand = json.load(f)
+            except (OSError, ValueError):
+                continue
+            if cand.get("workload") == args.workload and (pmc is None or cand.get("round", 0) >= pmc.get("round", 0)):
+                pmc, pmc_path = cand, os.path.relpath(path, ROOT)
         if dom_name:
             dk_ = kern[dom_name]
             achieved = dk_["bytes"] / (dk_["ms"] * 1e-3) / 1e9
@@ -263,7 +414,7 @@ def main():
                         "frac_of_measured_copy": None if not copy_gbs else round(achieved / copy_gbs, 4)}
             if pmc and pmc.get("workload") == args.workload and not args.n and dom_name in pmc["kernels"]:
                 roofline["traffic"] = pmc["kernels"][dom_name]["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/r01_pmc_traffic_enwik8like_1e8.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                roofline["traffic_source"] = pmc_path + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; a committed profile of this command, not this run)"
         fwd_ms = per["ms_sa"] + per["ms_bwt"]
         # BWT-forward roofline the way SURVEY 8(d) defines it: min(B_fwd formula, PMC-measured HBM bytes) / t_fwd against the 8 TB/s peak
         fwd_roofline = None
@@ -271,16 +422,29 @@ def main():
             P = 2 * -(-max(1, (n - 1).bit_length()) // 8)
             R = stats["rounds"]
             b_formula = n * (85 + R * (44 + 24 * P) + 6)
-            measured = sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for kk, v in pmc["kernels"].items() if not kk.startswith("k_dc_"))
+            fwd_kernels = {kk: v for kk, v in pmc["kernels"].items() if not kk.startswith("k_dc_") and not kk.startswith("k_ibwt_")}
+            measured = sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for v in fwd_kernels.values())
             ach = min(b_formula, measured) / (fwd_ms * 1e-3) / 1e9
+            # second figure, on USEFUL bytes: the kernels that gather single bytes / words (every gathered 64-byte line carries one
+            # wanted item) are capped at their algorithmic bytes (dk_stats.kernel_bytes of this run)
+            useful = 0.0
+            for kk, v in fwd_kernels.items():
+                per_step = v["hbm_bytes_per_launch"] * v["launches_per_step"]
+                if kk in ("k_bwt_gather", "k_bwt_gather_list", "k_round_local") and kk in kern:
+                    per_step = min(per_step, kern[kk]["bytes"] / k)
+                useful += per_step
+            ach_u = min(b_formula, useful) / (fwd_ms * 1e-3) / 1e9
             fwd_roofline = {"B_fwd_formula_bytes": b_formula, "rounds": R, "passes_P": P, "measured_hbm_bytes": round(measured),
-                            "t_fwd_ms": round(fwd_ms, 3), "achieved_GBs": round(ach, 1), "frac_of_8TBs": round(ach / HBM_PEAK_GBS, 4)}
+                            "t_fwd_ms": round(fwd_ms, 3), "achieved_GBs": round(ach, 1), "frac_of_8TBs": round(ach / HBM_PEAK_GBS, 4),
+                            "useful_hbm_bytes": round(useful), "achieved_useful_GBs": round(ach_u, 1),
+                            "frac_of_8TBs_useful": round(ach_u / HBM_PEAK_GBS, 4), "traffic_source": pmc_path}
         result = {
             "metric": "bwt_encode_MBps", "value": round(world * n * k / elapsed_max / 1e6, 3), "unit": "MB/s",
             "n_gpus": world, "steps": k, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed_max / k, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64 integer", "data": "synthetic",
             "config": {"workload": args.workload if not args.n else "wiki_like_%d" % n, "block_bytes": n, "model": args.model,
-                       "blocks_per_gpu": 1, "parallelism": "block-per-gpu x%d" % world},
+                       "blocks_per_gpu": 1, "parallelism": "block-per-gpu x%d" % world, "host_cpus_per_rank": share, "node_gpus": node_gpus,
+                       "gather": args.gather if world > 1 else "none"},
             "bwt_forward_MBps_per_gpu": round(n / (fwd_ms * 1e-3) / 1e6, 1),
             "device_forward_MBps_per_gpu": round(n / ((fwd_ms + per["ms_dc"]) * 1e-3) / 1e6, 1),
             "decode_MBps": None if decode_mbps is None else round(decode_mbps, 3),
@@ -293,6 +457,7 @@ def main():
             "roofline": roofline,
             "bwt_forward_roofline": fwd_roofline,
             "pipelined": pipelined,
+            "gather_ms": gather_ms,
             "datagen_s": round(t_gen, 2),
         }
         if dstats:

@@ -12,6 +12,7 @@ ERROR_NAMES = {-1: "DK_E_ARG", -2: "DK_E_NOMEM", -3: "DK_E_HIP", -4: "DK_E_CAPAC
                -6: "DK_E_STREAM", -7: "DK_E_INTERNAL", -8: "DK_E_NODEVICE"}
 MODEL_IDS = {"dark": 0, "exp": 1, "ybs": 2, "simple": 3, "rawdc": 4}
 NUM_KERNEL_SLOTS = 24
+DK_FLAG_HAS_FF, DK_FLAG_SINGLE_SYMBOL = 1, 2
 
 
 class Stats(C.Structure):
@@ -31,6 +32,7 @@ SIGNATURES = {
     "dk_ctx_destroy": (None, [_vp]),
     "dk_capacity": (_sz, [_vp]),
     "dk_last_consumed": (_sz, [_vp]),
+    "dk_last_block_flags": (C.c_uint, [_vp]),
     "dk_last_error": (C.c_char_p, [_vp]),
     "dk_suffix_array": (_i, [_vp, _vp, _sz, _vp]),
     "dk_bwt_forward": (_i, [_vp, _vp, _sz, _vp, _u32p]),
@@ -52,7 +54,7 @@ SIGNATURES = {
     "dk_bitcoder_encode": (_i, [_vp, _vp, _sz, _vp, _sz, _szp]),
     "dk_bitcoder_decode": (_i, [_vp, _sz, _vp, _sz, _vp]),
     "dk_stream_encode": (_i, [_i, _sz, _vp, _vp, _vp, _vp, _vp, _sz, C.c_uint32, _vp, _sz, _szp]),
-    "dk_stream_decode": (_i, [_i, _vp, _sz, _sz, _vp, _u32p, C.POINTER(_i)]),
+    "dk_stream_decode": (_i, [_i, _vp, _sz, _sz, _vp, _u32p, C.POINTER(_i), _szp]),
     "dk_set_profiling": (_i, [_vp, _i]),
     "dk_stats_reset": (_i, [_vp]),
     "dk_get_stats": (_i, [_vp, C.POINTER(Stats)]),

@@ -22,6 +22,16 @@ def _ptr(a):
     return C.c_void_p(int(a))
 
 
+def _inputs_ready(*tensors):
+    """Stream contract of the dk_dev_ entry points (include/dark_amd.h): device inputs must be complete before the call -- the library
+    runs on its own non-blocking stream and does not wait for the caller's.  For torch tensors: drain torch's current stream."""
+    for t in tensors:
+        if hasattr(t, "is_cuda") and t.is_cuda:
+            import torch
+            torch.cuda.current_stream(t.device).synchronize()
+            return
+
+
 def as_u8(x):
     if isinstance(x, np.ndarray):
         return np.ascontiguousarray(x, dtype=np.uint8)
@@ -72,6 +82,10 @@ class Context:
 
     def last_consumed(self):
         return int(self._lib.dk_last_consumed(self._h))
+
+    def last_block_flags(self):
+        """DK_FLAG_HAS_FF (1): the last block encode's input held byte 0xFF -> its stream cannot be decoded (reference format)"""
+        return int(self._lib.dk_last_block_flags(self._h))
 
     # ---- host-pointer stage calls ----
     def suffix_array(self, data):
@@ -131,17 +145,21 @@ class Context:
 
     # ---- device-resident calls (torch tensors or raw device addresses) ----
     def dev_suffix_array(self, d_in, n, d_sa_out):
+        _inputs_ready(d_in)
         self._ck(self._lib.dk_dev_suffix_array(self._h, _ptr(d_in), n, _ptr(d_sa_out)))
 
     def dev_bwt_forward(self, d_in, n, d_bwt_out):
+        _inputs_ready(d_in)
         origin = C.c_uint32(0)
         self._ck(self._lib.dk_dev_bwt_forward(self._h, _ptr(d_in), n, _ptr(d_bwt_out), C.byref(origin)))
         return int(origin.value)
 
     def dev_bwt_inverse(self, d_bwt, n, origin, d_out):
+        _inputs_ready(d_bwt)
         self._ck(self._lib.dk_dev_bwt_inverse(self._h, _ptr(d_bwt), n, int(origin), _ptr(d_out)))
 
     def dev_dc_encode(self, d_bwt, n, d_dist, d_sym, d_rank=None):
+        _inputs_ready(d_bwt)
         init = np.empty(256, dtype=np.uint32)
         m = C.c_size_t(0)
         self._ck(self._lib.dk_dev_dc_encode(self._h, _ptr(d_bwt), n, _ptr(init), _ptr(d_dist), _ptr(d_sym),
@@ -150,6 +168,7 @@ class Context:
 
     def dev_block_encode(self, model, d_in, n, out=None):
         """out: optional preallocated host uint8 array; returns a view of the coded stream"""
+        _inputs_ready(d_in)
         mid = model_id(model)
         if out is None:
             out = np.empty(2 * n + 4096, dtype=np.uint8)
@@ -159,6 +178,7 @@ class Context:
 
     def dev_batch_encode(self, model, d_blocks, sizes, host_threads=8, outs=None):
         """d_blocks: device tensors / addresses; returns a list of coded streams (views of `outs` when given)"""
+        _inputs_ready(*d_blocks[:1])
         count = len(d_blocks)
         if outs is None:
             outs = [np.empty(2 * int(n) + 4096, dtype=np.uint8) for n in sizes]

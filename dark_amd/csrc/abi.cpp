@@ -18,6 +18,7 @@ namespace {
 int begin_call(dk_ctx *ctx) {
     if (!ctx) return DK_E_ARG;
     ctx->err.clear();
+    ctx->last_flags = 0;
     ctx->ws_reset();
     if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(DK_E_HIP, "hipSetDevice(%d) failed", ctx->device);
     return DK_OK;
@@ -98,6 +99,12 @@ int forward_to_stream(dk_ctx *ctx, const uint8_t *d_text, size_t n, bool want_ct
     return DK_OK;
 }
 
+unsigned block_flags(const uint32_t init[256], size_t n) {
+    unsigned present = 0;
+    for (int c = 0; c < 256; ++c) present += init[c] < n ? 1u : 0u;
+    return (init[255] < n ? DK_FLAG_HAS_FF : 0u) | (present == 1 ? DK_FLAG_SINGLE_SYMBOL : 0u);
+}
+
 int block_encode_common(dk_ctx *ctx, int model_id, const uint8_t *d_text, size_t n, uint8_t *out, size_t out_cap, size_t *out_len) {
     if (model_max_block(model_id) == 0) return ctx->fail(DK_E_MODEL, "unknown model id %d", model_id);
     if (n > model_max_block(model_id))
@@ -105,6 +112,7 @@ int block_encode_common(dk_ctx *ctx, int model_id, const uint8_t *d_text, size_t
                          static_cast<unsigned long long>(model_max_block(model_id)));
     ForwardResult fr;
     DK_TRY(forward_to_stream(ctx, d_text, n, model_id == DK_MODEL_RAWDC, &fr));
+    ctx->last_flags = block_flags(fr.init, n);
     Timer t;
     DcStream s;
     s.n = n; s.init = fr.init; s.dist = fr.dist; s.sym = fr.sym; s.rank = fr.rank; s.run_end = fr.run_end; s.m = fr.m; s.origin = fr.origin;
@@ -193,6 +201,7 @@ void dk_ctx_destroy(dk_ctx *c) {
 
 size_t dk_capacity(const dk_ctx *ctx) { return ctx ? ctx->max_n : 0; }
 size_t dk_last_consumed(const dk_ctx *ctx) { return ctx ? ctx->last_consumed : 0; }
+unsigned dk_last_block_flags(const dk_ctx *ctx) { return ctx ? ctx->last_flags : 0; }
 const char *dk_last_error(const dk_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 // ---- device-resident entry points ------------------------------------------------------------------------------------
@@ -584,9 +593,10 @@ int dk_stream_encode(int model_id, size_t n, const uint32_t init[256], const uin
     s.n = n; s.init = init; s.dist = dist; s.sym = sym; s.rank = rank; s.run_end = run_end; s.m = m; s.origin = origin;
     return encode_block_stream(model_id, s, out, out_cap, out_len);
 }
-int dk_stream_decode(int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *bwt_out, uint32_t *origin, int *single_symbol) {
+int dk_stream_decode(int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *bwt_out, uint32_t *origin, int *single_symbol,
+                     size_t *consumed) {
     int single = 0;
-    int rc = decode_block_stream(model_id, in, in_len, n, bwt_out, origin, &single);
+    int rc = decode_block_stream(model_id, in, in_len, n, bwt_out, origin, &single, consumed);
     if (single_symbol) *single_symbol = single;
     return rc;
 }

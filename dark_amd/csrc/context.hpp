@@ -67,6 +67,7 @@ struct dk_ctx {
     std::vector<StageSlot> slots;
     int ensure_slot(size_t index, size_t bytes);
     std::string err;
+    unsigned last_flags = 0;   // DK_FLAG_* of the block the last block encode coded
     size_t last_consumed = 0;  // bytes of coded stream the last block decode read (records can be concatenated)
     dk_stats stats{};
     bool profiling = false;

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -432,8 +433,9 @@ int dc_rebuild(uint32_t const init[256], uint8_t *out, size_t n, F &&next_dist, 
         }
     }
     if (single) *single = alpha <= 1;
-    if (alpha <= 1) {  // "redundant alphabet": filled without reading any distance
-        std::memset(out, alpha ? order[0] : 0, n);
+    if (alpha == 0) return DK_E_STREAM;  // no symbol at all: a block of nothing but 0xFF bytes, which the header cannot carry
+    if (alpha == 1) {  // "redundant alphabet": filled without reading any distance
+        std::memset(out, order[0], n);
         return DK_OK;
     }
     // the positions are kept in list order beside the symbols (no next[order[r]] double load inside the sinking loop)
@@ -485,6 +487,14 @@ int read_stream(M &model, Decoder &d, size_t n, uint8_t *bwt_out, uint32_t *orig
         return model.decode(sym, d, *out) ? DK_OK : DK_E_STREAM;
     }, single);
     if (rc) return rc;
+    if (single && *single) {
+        // One-symbol block: bwt::dc::decode returns without asking for a distance, but the encoder wrote one (the end-of-block sweep
+        // entry of that symbol, src/block/dc.rs:82-85).  The reference goes on to read `origin` from it (DESIGN.md "Reference
+        // quirks"); here it is decoded and dropped, so that origin is the real one and consumed() is the length the encoder wrote --
+        // a following [u32 n][stream] record starts exactly there.
+        uint32_t sweep;
+        if (!model.decode(bwt_out[0], d, sweep)) return DK_E_STREAM;
+    }
     if (!model.decode(0, d, *origin)) return DK_E_STREAM;
     if (!d.finish()) return DK_E_STREAM;
     return DK_OK;
@@ -748,6 +758,30 @@ const Topology &topology() {
 // process death): ranks started by one launcher tend to sit in the same CCX when their first block is ready, and two pipelines
 // spinning in one CCX would halve each other.  The caller's own group is tried first, then the others by distance; when every
 // group is taken the call gets none (and codes on one thread).  The caller's affinity mask is restored on release.
+#if defined(__linux__)
+// Lock file of one L3 group.  It lives in a directory only this user can write ($XDG_RUNTIME_DIR, else /dev/shm/dark_amd.<uid>, mode 0700,
+// checked to be a real directory of ours), is opened without following links and must be a regular single-link file of ours: a name
+// planted by somebody else in a world-writable directory is never opened, chmod'ed or locked.  Coordination is therefore among the
+// processes of one user -- the ranks one launcher started, which is the case that matters.
+int open_group_lock(int group_id) {
+    std::string dir;
+    const char *xdg = getenv("XDG_RUNTIME_DIR");
+    struct stat st;
+    if (xdg && xdg[0] == '/' && lstat(xdg, &st) == 0 && S_ISDIR(st.st_mode) && st.st_uid == geteuid() && (st.st_mode & 022) == 0) {
+        dir = xdg;
+    } else {
+        dir = "/dev/shm/dark_amd." + std::to_string(static_cast<unsigned long>(geteuid()));
+        if (mkdir(dir.c_str(), 0700) != 0 && errno != EEXIST) return -1;
+        if (lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & 077) != 0) return -1;
+    }
+    const std::string path = dir + "/dark_amd.l3." + std::to_string(group_id) + ".lock";
+    const int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
+    if (fd < 0) return -1;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_nlink != 1 || st.st_uid != geteuid()) { close(fd); return -1; }
+    return fd;
+}
+#endif
+
 struct ThreadPair {
     int me = -1;
 #if defined(__linux__)
@@ -776,10 +810,8 @@ struct ThreadPair {
                 const size_t cores = (static_cast<size_t>(CPU_COUNT(&usable)) + topo.threads_per_core - 1) / topo.threads_per_core;
                 if (cores < static_cast<size_t>(cores_needed)) continue;
             }
-            const std::string path = "/dev/shm/dark_amd.l3." + std::to_string(g.id) + ".lock";
-            const int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+            const int fd = open_group_lock(g.id);
             if (fd >= 0) {
-                (void)fchmod(fd, 0666);  // other users' processes must be able to take part
                 if (flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); continue; }  // another pipeline lives here
             } else if (gi != static_cast<long>(own)) {
                 continue;  // cannot coordinate: stay at home rather than crowd somebody else's group

@@ -54,14 +54,17 @@ def stream_encode(model, n, init, dist, sym, origin, rank=None, run_end=None):
     return out[:ln.value].tobytes()
 
 
-def stream_decode(model, stream, n):
-    """host entropy stage alone (src/block/dc.rs:121-151) -> (bwt, origin, single_symbol)"""
+def stream_decode(model, stream, n, with_consumed=False):
+    """host entropy stage alone (src/block/dc.rs:121-151) -> (bwt, origin, single_symbol[, bytes consumed])"""
     lib = _lib.load()
     b = as_u8(stream)
     out = np.empty(n, dtype=np.uint8)
     origin = C.c_uint32(0)
     single = C.c_int(0)
-    rc = lib.dk_stream_decode(model_id(model), _ptr(b), len(b), n, _ptr(out), C.byref(origin), C.byref(single))
+    used = C.c_size_t(0)
+    rc = lib.dk_stream_decode(model_id(model), _ptr(b), len(b), n, _ptr(out), C.byref(origin), C.byref(single), C.byref(used))
     if rc:
         raise DarkError(rc)
+    if with_consumed:
+        return out, int(origin.value), bool(single.value), int(used.value)
     return out, int(origin.value), bool(single.value)

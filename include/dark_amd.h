@@ -9,6 +9,10 @@
  *     dk_last_error() gives the text of the last failure on that context;
  *   - "host" entry points take caller-owned host pointers valid for the call; "dk_dev_" entry points take
  *     caller-owned DEVICE pointers (hipMalloc'ed on the context's GPU, e.g. torch tensor .data_ptr());
+ *   - stream contract of the dk_dev_ entry points: the library works on its own non-blocking HIP stream and synchronises it
+ *     before returning, so outputs are complete on return.  It does NOT order its work after the caller's streams: device
+ *     INPUTS must be complete (the producing stream synchronised) before the call.  dark_amd/context.py does that for
+ *     torch tensors (torch.cuda.current_stream().synchronize());
  *   - n == 0 is an error (the reference panics at src/saca.rs:107); n must be <= dk_capacity();
  *   - there is no CPU fallback: without a GPU dk_ctx_create fails.  Suffix sorting, BWT, DC distances and
  *     the inverse BWT run on the GPU; the adaptive range coder and dc::decode are serial by construction
@@ -79,6 +83,15 @@ int dk_block_decode(dk_ctx *ctx, int model_id, const uint8_t *in, size_t in_len,
  * 4 priming bytes + one per renormalisation shift).  Lets a caller walk concatenated [u32 n][stream] records -- the
  * multi-block extension of the single-block file of src/main.rs:70,102. */
 size_t dk_last_consumed(const dk_ctx *ctx);
+/* Properties of the block the last dk_block_encode / dk_dev_block_encode on this context coded (0 after any other call):
+ *   DK_FLAG_HAS_FF         the block contains byte 0xFF.  The stream is bit-exact with the reference's, and like the reference's it
+ *                          cannot be decoded: the init-table header never transmits symbol 0xFF (src/block/dc.rs:57,60,73,127).
+ *                          A front end should refuse or warn (dark_amd/cli.py does) instead of writing an archive that is lost.
+ *   DK_FLAG_SINGLE_SYMBOL  one distinct symbol: the reference's decoder mis-reads `origin` for such a block;
+ *                          this library's decoder returns all n bytes. */
+#define DK_FLAG_HAS_FF 1u
+#define DK_FLAG_SINGLE_SYMBOL 2u
+unsigned dk_last_block_flags(const dk_ctx *ctx);
 
 /* ---- device-resident entry points (inputs already in HBM; used by pipelines and by bench.py) ----------------- */
 int dk_dev_suffix_array(dk_ctx *ctx, const uint8_t *d_in, size_t n, uint32_t *d_sa_out);
@@ -121,7 +134,7 @@ int dk_stream_encode(int model_id, size_t n, const uint32_t init[256], const uin
                      const uint8_t *rank, const uint32_t *run_end, size_t m, uint32_t origin,
                      uint8_t *out, size_t out_cap, size_t *out_len);
 int dk_stream_decode(int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *bwt_out, uint32_t *origin,
-                     int *single_symbol);
+                     int *single_symbol, size_t *consumed /* may be NULL: bytes of `in` read = the length the encoder wrote */);
 
 /* ---- measurement ------------------------------------------------------------------------------------------ */
 #define DK_NUM_KERNEL_SLOTS 24

@@ -106,6 +106,25 @@ def test_entropy_stage_seeded(orc):
                 assert o2 == origin
 
 
+def test_consumed_equals_written_also_for_one_symbol_blocks(orc):
+    # records of a multi-block file are walked by "bytes consumed"; for a one-symbol block the reference's dc::decode returns
+    # before the sweep distance the encoder wrote, so the decoder must read and drop it or the next record header is missed by 2-4 bytes
+    cases = [np.zeros(1000, np.uint8), np.full(7, 65, np.uint8), np.frombuffer(b"abracadabra", np.uint8), np.array([3, 3], np.uint8),
+             np.frombuffer(b"ab" * 50, np.uint8)]
+    for t in cases:
+        n = len(t)
+        for m in MODELS:
+            s = orc.block_dc_encode(m, t)
+            bwt, origin = orc.bwt_forward(t)
+            b2, o2, single, used = model.stream_decode(m, s + b"\x5a" * 9, n, with_consumed=True)  # trailing bytes = the next record
+            assert used == len(s), (m, n, used, len(s))
+            assert (b2 == bwt).all() and o2 == origin
+            assert single == (len(set(t.tolist())) == 1)
+    with pytest.raises(dark_amd.DarkError):  # nothing but 0xFF: no symbol reaches the decoder -> error, not a block of zeros
+        t = np.full(50, 255, np.uint8)
+        model.stream_decode("dark", orc.block_dc_encode("dark", t), 50)
+
+
 def test_dc_decode_host(orc):
     lib = dark_amd.load_library()
     for t in seeded_inputs(seed=29, count=30):

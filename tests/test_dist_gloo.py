@@ -73,3 +73,39 @@ def test_two_rank_block_parallel_gather():
     by = {r[0]: r for r in results}
     assert by["rank0"][1] is True
     assert len(by["rank0"][2]) == 2 and by["rank0"][2][1] == by["rank1"][2][0]
+
+
+def _run_bench(cmd):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(300)
+def test_bench_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` with no launcher must run TWO ranks (it used to run one and report n_gpus 1).  CPU stub of
+    the exchange: same launcher, same exchange_streams() code path, backend gloo, streams from the product's host coder."""
+    res = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--stub-exchange"])
+    assert res["n_gpus"] == 2 and res["gathered_streams_decode"] is True and len(res["stream_bytes"]) == 2
+
+
+@pytest.mark.timeout(300)
+def test_bench_under_torchrun():
+    """the driver's documented N>1 command line: torch.distributed.run starts the ranks, bench.py must not spawn again"""
+    res = _run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                      "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--stub-exchange"])
+    assert res["n_gpus"] == 2 and res["gathered_streams_decode"] is True
+
+
+def test_bench_rejects_mismatched_world():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "3", "--stub-exchange"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

@@ -26,13 +26,15 @@ def _histogram(t):
     return torch.bincount(t.to(torch.int64), minlength=256)
 
 
-@pytest.mark.parametrize("workload", ["enwik8_like_1e8", "acgt_2p28", "random_2p30"])
+@pytest.mark.parametrize("workload", ["enwik8_like_1e8", "acgt_2p28", "enwik9_block_125e6", "random_2p30"])
 def test_fullsize_properties(workload):
     rng = np.random.default_rng(7)
     if workload == "enwik8_like_1e8":
         block = datagen.wiki_like(100_000_000, 2)
     elif workload == "acgt_2p28":
         block = datagen.acgt(1 << 28, 3)
+    elif workload == "enwik9_block_125e6":
+        block = datagen.wiki_like(125_000_000, 41)  # BASELINE configs[3]: one of the 8 blocks (seed 40 is in test_gpu_configs.py)
     else:
         block = datagen.random_bytes(1 << 30, 50)
     n = len(block)
