@@ -11,7 +11,7 @@ DK_E_ARG, DK_E_NOMEM, DK_E_HIP, DK_E_CAPACITY, DK_E_MODEL, DK_E_STREAM, DK_E_INT
 ERROR_NAMES = {-1: "DK_E_ARG", -2: "DK_E_NOMEM", -3: "DK_E_HIP", -4: "DK_E_CAPACITY", -5: "DK_E_MODEL",
                -6: "DK_E_STREAM", -7: "DK_E_INTERNAL", -8: "DK_E_NODEVICE"}
 MODEL_IDS = {"dark": 0, "exp": 1, "ybs": 2, "simple": 3, "rawdc": 4}
-NUM_KERNEL_SLOTS = 24
+NUM_KERNEL_SLOTS = 32
 DK_FLAG_HAS_FF, DK_FLAG_SINGLE_SYMBOL = 1, 2
 
 

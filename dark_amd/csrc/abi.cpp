@@ -32,8 +32,8 @@ int check_n(dk_ctx *ctx, size_t n) {
     return DK_OK;
 }
 size_t workspace_bytes(size_t max_n) {
-    // text copy n + bwt n + DC arrays 10 n + SA 4 n + suffix-sort temporaries 64 n + per-tile tables (< n) + slack
-    return 84 * max_n + (48u << 20);
+    // text copy n + bwt n + DC arrays 10 n + SA 4 n + suffix-sort temporaries 66 n + per-tile tables (< n) + slack
+    return 86 * max_n + (48u << 20);
 }
 struct ScopedCall {
     dk_ctx *c;
@@ -177,6 +177,7 @@ int dk_ctx_create(int hip_device, size_t max_n, dk_ctx **out) {
     ok = ok && hipMalloc(reinterpret_cast<void **>(&c->d_mail), 1024 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&c->h_mail), 1024 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMemset(c->d_mail, 0, 1024 * sizeof(uint32_t)) == hipSuccess;
+    for (hipEvent_t &e : c->round_ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         dk_ctx_destroy(c);
         return DK_E_NOMEM;
@@ -190,6 +191,7 @@ void dk_ctx_destroy(dk_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->round_ev) if (e) (void)hipEventDestroy(e);
     if (c->ws) (void)hipFree(c->ws);
     if (c->d_mail) (void)hipFree(c->d_mail);
     if (c->h_mail) (void)hipHostFree(c->h_mail);

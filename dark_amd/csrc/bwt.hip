@@ -351,7 +351,7 @@ int bwt_inverse_device(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t ori
     for (int it = 0; it < steps; ++it) {
         if (it == steps - 1) DK_HIP(ctx, hipMemsetAsync(d_pending, 0, sizeof(uint32_t), st));
         {
-            LaunchScope ls(ctx, K_IBWT_RANK, 24.0 * nsplit);
+            LaunchScope ls(ctx, K_IBWT_JUMP, 24.0 * nsplit);
             k_ibwt_jump<<<dim3(div_up(nsplit, 256)), dim3(256), 0, st>>>(nxt, acc, nxt_alt, acc_alt, nsplit, d_pending);
         }
         std::swap(nxt, nxt_alt);

@@ -20,23 +20,29 @@ enum KernelSlot : int {
     K_SYM_HIST = 0,
     K_PACK_KEYS,
     K_RADIX_HIST,
-    K_RADIX_SCAN,
+    K_RADIX_SCAN,      // k_radix_scan_a + _b + _c (one bracket)
     K_RADIX_SCATTER,
     K_RERANK_REDUCE,
     K_RERANK_SCAN,
     K_RERANK_APPLY,
-    K_BUILD_KEYS,
+    K_ROUND_LOCAL,
     K_BWT_GATHER,
     K_DC_SUMMARY,
-    K_DC_SCAN,
+    K_DC_CARRY,        // k_dc_runscan + k_dc_carry_a/_b/_c + k_fill_u32
     K_DC_MAIN,
     K_DC_SWEEP,
-    K_IBWT_HIST,
+    K_IBWT_HIST,       // k_ibwt_hist + k_ibwt_scan_a/_b/_c
     K_IBWT_LF,
     K_IBWT_WALK,
-    K_IBWT_RANK,
+    K_IBWT_JUMP,
     K_IBWT_EMIT,
-    K_MISC,
+    K_BUCKET_STORE,
+    K_BIG_CLASSIFY,    // k_big_reduce + k_big_spine + k_big_apply
+    K_BIG_BACK,
+    K_PREFIX_PROBE,
+    K_PLACE_ACTIVE,    // k_place_active + k_rank_active
+    K_PLATEAU_SORT,
+    K_PLATEAU_RANKS,   // k_plateau_ranks, k_to_inplace, k_plateau_count/_scan/_compact
     K_SLOT_COUNT
 };
 static_assert(K_SLOT_COUNT <= DK_NUM_KERNEL_SLOTS, "grow DK_NUM_KERNEL_SLOTS");
@@ -71,6 +77,7 @@ struct dk_ctx {
     size_t last_consumed = 0;  // bytes of coded stream the last block decode read (records can be concatenated)
     dk_stats stats{};
     bool profiling = false;
+    hipEvent_t round_ev[8] = {};  // suffix sort: one per in-place round in flight (live count read back one round late)
     std::vector<hipEvent_t> ev_pool;
     struct Pending { int slot; hipEvent_t a, b; double bytes; };
     std::vector<Pending> ev_pending;

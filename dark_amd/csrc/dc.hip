@@ -431,7 +431,7 @@ int dc_encode_device(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t init_
         k_dc_summary<<<dim3(nblocks), dim3(DC_BLOCK), 0, st>>>(d_bwt, n, ntiles, tile_last, tile_lrun, tile_runs);
     }
     {
-        LaunchScope ls(ctx, K_DC_SCAN, 3.0 * 2048.0 * ntiles);
+        LaunchScope ls(ctx, K_DC_CARRY, 3.0 * 2048.0 * ntiles);
         k_dc_runscan<<<dim3(1), dim3(1024), 0, st>>>(tile_runs, ntiles, ctx->d_mail);
         k_dc_carry_a<<<dim3(nchunks), dim3(256), 0, st>>>(tile_last, tile_lrun, tile_runs, ntiles, tpc, chunk_last, chunk_lrun);
         k_dc_carry_b<<<dim3(1), dim3(256), 0, st>>>(chunk_last, chunk_lrun, nchunks);

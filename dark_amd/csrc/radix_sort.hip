@@ -704,7 +704,7 @@ int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, 
                                                                               nullptr, nullptr, static_cast<uint32_t>(ntiles));
     }
     {
-        LaunchScope ls(ctx, K_MISC, 12.0 * count);
+        LaunchScope ls(ctx, K_BUCKET_STORE, 12.0 * count);
         // 72 KiB of (unused) dynamic LDS caps residency at 2 workgroups per CU: ~260 K pairs in flight per XCD, less than one
         // bucket, so the lines of the bucket being written stay in that XCD's 4 MiB L2 until they are complete
         static const size_t lds_cap = [] { const char *e = getenv("DK_BUCKET_LDS"); return e ? static_cast<size_t>(atoi(e)) : size_t(72 * 1024); }();

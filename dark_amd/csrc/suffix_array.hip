@@ -173,16 +173,6 @@ __global__ __launch_bounds__(256) void k_rank_active(const uint32_t *__restrict_
     if (a < count) rank[act_idx[a]] = act_pos[gstart[act_gid[a]]];
 }
 
-// BWT symbols of the positions listed (the suffixes that were not final after the initial sort of the short-prefix path)
-__global__ __launch_bounds__(256) void k_bwt_gather_list(const uint8_t *__restrict__ t, const uint32_t *__restrict__ sa, size_t n,
-                                                          const uint32_t *__restrict__ list, size_t count, uint8_t *__restrict__ bwt,
-                                                          uint32_t *__restrict__ origin) {
-    const size_t a = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (a >= count) return;
-    const uint32_t p = list[a], suffix = sa[p];
-    if (suffix == 0) { bwt[p] = t[n - 1]; *origin = p; } else { bwt[p] = t[suffix - 1]; }
-}
-
 // ---- rerank: three kernels sharing the per-slot flag logic ------------------------------------------------------
 struct RerankAgg { uint32_t surv, heads, last_head, pad; };
 
@@ -291,9 +281,19 @@ __global__ __launch_bounds__(1024) void k_rerank_scan(RerankAgg *__restrict__ ag
     if (tid == 0) { mail[0] = tot_s; mail[1] = tot_h; gstart[tot_h] = tot_s; }  // sentinel: one past the last group
 }
 
-// Short-prefix path, first rerank: the keys' low cmp_shift bits are not compared; when bwt is given they hold the code of the symbol in
-// front of the suffix, and every suffix that is final writes its BWT symbol (inv_code: code -> byte) and, for suffix 0, the origin.
-struct FirstBwt { int cmp_shift; uint8_t *bwt; const uint8_t *inv_code; uint32_t *origin; };
+// BWT on the way.  When the caller wants L, the initial keys carry, below the sorted bits, the code of the symbol in FRONT of the suffix
+// (cmp_shift = 8 low bits that take no part in any comparison).  The first rerank turns it into the symbol itself: a suffix that is
+// final writes L[its SA position] (and, for suffix 0, the origin); a suffix that stays active takes the symbol along in a byte list
+// beside (idx, pos, gid) -- sym_in / sym_out in the later rounds -- and writes it when it becomes final.  No gather from the text, ever.
+struct BwtCarry {
+    int cmp_shift;            // first rerank only: low key bits outside the comparison
+    uint8_t *bwt;             // L (nullptr: the caller wants the suffix array only)
+    const uint8_t *inv_code;  // first rerank: code -> byte
+    uint32_t *origin;
+    const uint8_t *sym_in;    // later reranks: symbol in front of the suffix in slot a
+    uint8_t *sym_out;         // compacted with the active list
+};
+constexpr BwtCarry NO_CARRY{0, nullptr, nullptr, nullptr, nullptr, nullptr};
 
 // pos_in == nullptr means slot a sits at SA position a (first rerank, straight after the initial sort).
 // All tile inputs arrive through LDS with lane-contiguous loads; the compacted outputs leave through LDS the same way.
@@ -305,12 +305,12 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
                                                             uint32_t *__restrict__ sa, uint32_t *__restrict__ out_idx,
                                                             uint32_t *__restrict__ out_pos, uint32_t *__restrict__ out_gid,
                                                             uint32_t *__restrict__ gstart, uint32_t *__restrict__ headpos_out,
-                                                            FirstBwt fb) {
+                                                            BwtCarry bc) {
     __shared__ uint64_t s_key[RR_TILE + 2];                       // later reused: compacted idx | pos
     __shared__ __attribute__((aligned(16))) uint32_t s_idx[RR_TILE];
     __shared__ __attribute__((aligned(16))) uint32_t s_pos[FIRST ? 4 : RR_TILE];
     __shared__ __attribute__((aligned(8))) uint8_t s_flag[RR_TILE];
-    __shared__ __attribute__((aligned(8))) uint8_t s_low[FIRST ? RR_TILE : 8];  // FIRST + fb.bwt: previous-symbol codes of the tile
+    __shared__ __attribute__((aligned(8))) uint8_t s_low[RR_TILE];  // bc.bwt: FIRST: previous-symbol codes of the tile; later: compacted symbols
     __shared__ uint32_t s_tmp[RR_WAVES + 1];
     const int tid = threadIdx.x;
     const size_t b0 = static_cast<size_t>(blockIdx.x) * RR_TILE;
@@ -324,25 +324,30 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
         }
     }
     // ends with a barrier: s_idx / s_pos (/ s_low) are visible, s_key is free
-    stage_flags(keys, count, b0, gshift, s_key, s_flag, FIRST ? fb.cmp_shift : 0, (FIRST && fb.bwt) ? s_low : nullptr);
+    stage_flags(keys, count, b0, gshift, s_key, s_flag, FIRST ? bc.cmp_shift : 0, (FIRST && bc.bwt) ? s_low : nullptr);
     const size_t a0 = b0 + static_cast<size_t>(tid) * RR_IPT;
     const uint64_t fl = *reinterpret_cast<const uint64_t *>(s_flag + tid * RR_IPT);
-    if (FIRST && fb.bwt && a0 < count) {
-        // singletons of the short-prefix path are final AND carry their BWT symbol: eight of them in a row leave as one 8-byte store
-        const uint64_t low8 = *reinterpret_cast<const uint64_t *>(s_low + tid * RR_IPT);
-        uint64_t sym8 = 0;
-        bool all_final = a0 + RR_IPT <= count;
+    uint64_t sym8 = 0;  // bc.bwt: the symbols in front of this thread's eight suffixes
+    if (bc.bwt && a0 < count) {
+        if (FIRST) {
+            const uint64_t low8 = *reinterpret_cast<const uint64_t *>(s_low + tid * RR_IPT);
 #pragma unroll
-        for (int j = 0; j < RR_IPT; ++j) {
-            sym8 |= static_cast<uint64_t>(fb.inv_code[(low8 >> (8 * j)) & 0xFFu]) << (8 * j);
-            all_final = all_final && !((fl >> (8 * j)) & F_SURV);
-        }
-        if (all_final && ((reinterpret_cast<uintptr_t>(fb.bwt) + a0) & 7) == 0) {
-            *reinterpret_cast<uint64_t *>(fb.bwt + a0) = sym8;
+            for (int j = 0; j < RR_IPT; ++j) sym8 |= static_cast<uint64_t>(bc.inv_code[(low8 >> (8 * j)) & 0xFFu]) << (8 * j);
+            // slot a sits at SA position a: eight finals in a row leave as one 8-byte store
+            bool all_final = a0 + RR_IPT <= count;
+#pragma unroll
+            for (int j = 0; j < RR_IPT; ++j) all_final = all_final && !((fl >> (8 * j)) & F_SURV);
+            if (all_final && ((reinterpret_cast<uintptr_t>(bc.bwt) + a0) & 7) == 0) {
+                *reinterpret_cast<uint64_t *>(bc.bwt + a0) = sym8;
+            } else {
+#pragma unroll
+                for (int j = 0; j < RR_IPT; ++j)
+                    if (a0 + j < count && !((fl >> (8 * j)) & F_SURV)) bc.bwt[a0 + j] = static_cast<uint8_t>(sym8 >> (8 * j));
+            }
+        } else if (a0 + RR_IPT <= count) {
+            sym8 = *reinterpret_cast<const uint64_t *>(bc.sym_in + a0);  // a0 is a multiple of 8, the list is 256-byte aligned
         } else {
-#pragma unroll
-            for (int j = 0; j < RR_IPT; ++j)
-                if (a0 + j < count && !((fl >> (8 * j)) & F_SURV)) fb.bwt[a0 + j] = static_cast<uint8_t>(sym8 >> (8 * j));
+            for (int j = 0; j < RR_IPT && a0 + j < count; ++j) sym8 |= static_cast<uint64_t>(bc.sym_in[a0 + j]) << (8 * j);
         }
     }
     uint32_t ns, nh, lh;
@@ -369,8 +374,9 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
             my_pos[0] = p0.x; my_pos[1] = p0.y; my_pos[2] = p0.z; my_pos[3] = p0.w; my_pos[4] = p1.x; my_pos[5] = p1.y; my_pos[6] = p1.z; my_pos[7] = p1.w;
         }
     }
-    __syncthreads();              // every thread holds its slice of s_idx in registers:
-    uint32_t *s_ogid = s_idx;     // the array now collects the compacted group ids (35 KiB of LDS: four workgroups per CU)
+    __syncthreads();              // every thread holds its slice of s_idx (and of s_low) in registers:
+    uint32_t *s_ogid = s_idx;     // the array now collects the compacted group ids (37 KiB of LDS: four workgroups per CU)
+    uint8_t *s_osym = s_low;      // and this one the compacted symbols
 #pragma unroll
     for (int j = 0; j < RR_IPT; ++j) {
         const size_t a = a0 + j;
@@ -385,12 +391,16 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
         else if (rank && !(el & 1u)) rank[suffix] = head_pos;  // members of a group that kept its head keep their rank: no scatter
         if (!(f & F_SURV)) {
             sa[my_pos[j]] = suffix;  // the group is a singleton: this suffix is in its final place
-            if (FIRST && fb.bwt && suffix == 0) *fb.origin = my_pos[j];
+            if (bc.bwt) {
+                if (!FIRST) bc.bwt[my_pos[j]] = static_cast<uint8_t>(sym8 >> (8 * j));
+                if (suffix == 0) *bc.origin = my_pos[j];
+            }
         } else {
             if (f & F_HEAD) { gstart[eh] = base.surv + es; ++eh; }  // first slot of the surviving group in the new active list
             s_oidx[es] = suffix;
             s_opos[es] = my_pos[j];
             s_ogid[es] = eh - 1;
+            if (bc.bwt) s_osym[es] = static_cast<uint8_t>(sym8 >> (8 * j));
             ++es;
         }
     }
@@ -399,6 +409,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
         out_idx[base.surv + o] = s_oidx[o];
         out_pos[base.surv + o] = s_opos[o];
         out_gid[base.surv + o] = s_ogid[o];
+        if (bc.bwt) bc.sym_out[base.surv + o] = s_osym[o];
     }
 }
 
@@ -407,7 +418,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
 // rank array, so the apply phase only writes SA.
 int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_t *pos_in, size_t count, int gshift, uint32_t *rank,
            uint32_t *sa, uint32_t *out_idx, uint32_t *out_pos, uint32_t *out_gid, uint32_t *gstart, uint32_t *headpos_out = nullptr,
-           bool probe_active = false, bool *ranks_written = nullptr, FirstBwt fb = FirstBwt{0, nullptr, nullptr, nullptr}) {
+           bool probe_active = false, bool *ranks_written = nullptr, BwtCarry fb = NO_CARRY) {
     const size_t ntiles = div_up(count, RR_TILE);
     const size_t mark = ctx->ws_mark();
     RerankAgg *agg = ctx->ws_alloc<RerankAgg>(ntiles);
@@ -529,7 +540,8 @@ __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__rest
                                                           const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ bigstart,
                                                           const uint32_t *__restrict__ rank, uint32_t n, uint32_t h, int kbits,
                                                           size_t count, uint64_t *__restrict__ key_out, uint32_t *__restrict__ idx_out,
-                                                          uint64_t *__restrict__ bkeys, uint32_t *__restrict__ bidx, TextSource ts) {
+                                                          uint64_t *__restrict__ bkeys, uint32_t *__restrict__ bidx, TextSource ts,
+                                                          const uint8_t *__restrict__ sym_in, uint8_t *__restrict__ sym_out) {
     using R2 = typename std::conditional<TEXT, uint64_t, uint32_t>::type;
     __shared__ R2 s_r2[LS_TILE + 2 * LS_MAX];
     auto second = [&](uint32_t suffix) -> R2 {
@@ -577,6 +589,7 @@ __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__rest
             }
             key_out[gs + before] = key;
             idx_out[gs + before] = my_idx[k];
+            if (sym_in) sym_out[gs + before] = sym_in[a];  // the symbol in front of the suffix travels with it (BwtCarry)
         } else {
             const uint32_t bo = bigstart[g] + (static_cast<uint32_t>(a) - gs);
             bkeys[bo] = key;
@@ -585,17 +598,180 @@ __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__rest
     }
 }
 
-// sorted big list -> back into the slots of the big groups (a sorted element stays inside its group's slot range)
+// sorted big list -> back into the slots of the big groups (a sorted element stays inside its group's slot range).  sym_out (BwtCarry):
+// the few members of big groups fetch the symbol in front of their suffix from the text again instead of dragging it through the sort.
 __global__ __launch_bounds__(256) void k_big_back(const uint64_t *__restrict__ bkeys, const uint32_t *__restrict__ bidx, size_t nbig,
                                                    int kbits, const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ bigstart,
-                                                   uint64_t *__restrict__ key_out, uint32_t *__restrict__ idx_out) {
+                                                   uint64_t *__restrict__ key_out, uint32_t *__restrict__ idx_out,
+                                                   const uint8_t *__restrict__ text, uint32_t n, uint8_t *__restrict__ sym_out) {
     const size_t bo = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (bo >= nbig) return;
     const uint64_t key = bkeys[bo];
     const uint32_t g = static_cast<uint32_t>(key >> kbits);
     const uint32_t a = gstart[g] + (static_cast<uint32_t>(bo) - bigstart[g]);
+    const uint32_t suffix = bidx[bo];
     key_out[a] = key;
-    idx_out[a] = bidx[bo];
+    idx_out[a] = suffix;
+    if (sym_out) sym_out[a] = text[suffix ? suffix - 1 : n - 1];
+}
+
+// ---- plateau rounds: every group has at most LS_MAX members ---------------------------------------------------------------------
+// Once a round ends without a big group there will never be one again (groups only split), and what is left are typically the
+// suffixes inside long repeats: the list shrinks slowly for log2(repeat length) rounds.  These rounds run on an IN-PLACE list:
+//   idx[a]   suffix in slot a; bit 31 set = the slot is dead (its suffix is final)
+//   meta[a]  offset of the slot inside its group (6 bits) | group size - 1 (6 bits) << 6 | PL_MOVED << 12
+//   pos[a]   SA position of slot a (never changes: members move only inside their group's slot range)
+// One kernel per round sorts every group inside LDS by the rank of the suffix h further on and writes each member to its place
+// (ping-pong idx / meta / sym): its new group is the run of members with the same secondary rank.  No compaction, no global scan,
+// no host round trip: the number of live slots comes back one round late.  Ranks are updated by a second, tiny kernel: updating
+// them inside the first would let another workgroup see the new rank of one suffix and the old rank of its group mate -- an order
+// that may contradict both the h-order and the 2h-order.
+constexpr uint32_t PL_DEAD = 0xFFFFFFFFu, PL_DEAD_BIT = 0x80000000u;
+constexpr uint32_t PL_MOVED = 1u << 12;  // the slot's group got a new head this round: its members' ranks change
+
+__global__ __launch_bounds__(256) void k_to_inplace(const uint32_t *__restrict__ gid, const uint32_t *__restrict__ gstart, size_t count,
+                                                     uint16_t *__restrict__ meta) {
+    const size_t a = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (a >= count) return;
+    const uint32_t g = gid[a];
+    const uint32_t gs = gstart[g], ge = gstart[g + 1];
+    meta[a] = static_cast<uint16_t>((static_cast<uint32_t>(a) - gs) | ((ge - gs - 1u) << 6));
+}
+
+__global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__restrict__ idx_in, const uint16_t *__restrict__ meta_in,
+                                                           const uint8_t *__restrict__ sym_in, const uint32_t *__restrict__ pos,
+                                                           const uint32_t *__restrict__ rank, uint32_t n, uint32_t h, size_t slots,
+                                                           uint32_t *__restrict__ idx_out, uint16_t *__restrict__ meta_out,
+                                                           uint8_t *__restrict__ sym_out, uint32_t *__restrict__ sa,
+                                                           uint8_t *__restrict__ bwt, uint32_t *__restrict__ origin,
+                                                           uint32_t *__restrict__ live) {
+    __shared__ uint32_t s_r2[LS_TILE + 2 * LS_MAX];
+    __shared__ uint32_t s_cnt[RR_WAVES];
+    const int tid = threadIdx.x;
+    const size_t b0 = static_cast<size_t>(blockIdx.x) * LS_TILE;
+    uint32_t my_idx[LS_IPT], my_r2[LS_IPT];
+#pragma unroll
+    for (int k = 0; k < LS_IPT; ++k) {
+        const size_t a = b0 + static_cast<size_t>(k) * LS_BLOCK + tid;
+        my_idx[k] = a < slots ? idx_in[a] : PL_DEAD;
+        my_r2[k] = (my_idx[k] & PL_DEAD_BIT) ? 0u : rank2_of(rank, my_idx[k], n, h);
+        s_r2[LS_MAX + k * LS_BLOCK + tid] = my_r2[k];
+    }
+    if (tid < 2 * LS_MAX) {  // halo: LS_MAX slots before the tile, LS_MAX after
+        const bool left = tid < LS_MAX;
+        const size_t off = left ? static_cast<size_t>(tid) : static_cast<size_t>(LS_TILE) + LS_MAX + (tid - LS_MAX);
+        if (b0 + off >= static_cast<size_t>(LS_MAX) && b0 + off - LS_MAX < slots) {
+            const uint32_t v = idx_in[b0 + off - LS_MAX];
+            s_r2[off] = (v & PL_DEAD_BIT) ? 0u : rank2_of(rank, v, n, h);
+        }
+    }
+    __syncthreads();
+    uint32_t alive = 0;
+#pragma unroll
+    for (int k = 0; k < LS_IPT; ++k) {
+        const size_t a = b0 + static_cast<size_t>(k) * LS_BLOCK + tid;
+        if (a >= slots) continue;
+        if (my_idx[k] & PL_DEAD_BIT) { idx_out[a] = PL_DEAD; continue; }  // a dead slot is never inside a live group's range
+        const uint32_t m = meta_in[a];
+        const uint32_t gs = static_cast<uint32_t>(a) - (m & 63u), ge = gs + ((m >> 6) & 63u) + 1u;
+        const uint32_t mine = my_r2[k];
+        const uint32_t base = static_cast<uint32_t>(LS_MAX) - static_cast<uint32_t>(b0);  // LDS index of slot b = b + base (mod 2^32)
+        uint32_t less = 0, eq_before = 0, eq = 0;
+        for (uint32_t b = gs; b < ge; ++b) {
+            const uint32_t v = s_r2[b + base];
+            less += v < mine;
+            eq += v == mine;
+            eq_before += (v == mine) && b < static_cast<uint32_t>(a);
+        }
+        const uint32_t dest = gs + less + eq_before;
+        const uint32_t moved = less ? PL_MOVED : 0u;  // new head slot gs + less: the rank becomes pos[gs + less]
+        meta_out[dest] = static_cast<uint16_t>(eq_before | ((eq - 1u) << 6) | moved);
+        if (eq == 1) {  // alone in its new group: final
+            const uint32_t p = pos[dest];
+            sa[p] = my_idx[k];
+            if (sym_in) bwt[p] = sym_in[a];
+            if (origin && my_idx[k] == 0) *origin = p;
+            idx_out[dest] = my_idx[k] | PL_DEAD_BIT;  // k_plateau_ranks still needs the suffix; dead for every later round
+        } else {
+            idx_out[dest] = my_idx[k];
+            if (sym_in) sym_out[dest] = sym_in[a];
+            ++alive;
+        }
+    }
+    alive = wave_sum(alive);
+    if ((tid & 63) == 0) s_cnt[tid >> 6] = alive;
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (t) atomicAdd(live, t);
+    }
+}
+
+// the rank updates of the round k_plateau_sort just ran: members of a group with a new head get that head's SA position
+__global__ __launch_bounds__(256) void k_plateau_ranks(const uint32_t *__restrict__ idx, const uint16_t *__restrict__ meta,
+                                                        const uint32_t *__restrict__ pos, size_t slots, uint32_t *__restrict__ rank) {
+    const size_t a = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (a >= slots) return;
+    const uint32_t v = idx[a];
+    if (v == PL_DEAD) return;
+    const uint32_t m = meta[a];
+    if (m & PL_MOVED) rank[v & ~PL_DEAD_BIT] = pos[a - (m & 63u)];
+}
+
+// compaction of the in-place list (when most of its slots are dead): live slots keep their order, so groups stay contiguous
+__global__ __launch_bounds__(RR_BLOCK) void k_plateau_count(const uint32_t *__restrict__ idx, size_t slots, uint32_t *__restrict__ tile_live) {
+    __shared__ uint32_t s_cnt[RR_WAVES];
+    const size_t b0 = static_cast<size_t>(blockIdx.x) * RR_TILE;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < RR_IPT; ++k) {
+        const size_t a = b0 + static_cast<size_t>(k) * RR_BLOCK + threadIdx.x;
+        c += (a < slots && !(idx[a] & PL_DEAD_BIT)) ? 1u : 0u;
+    }
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_live[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+__global__ __launch_bounds__(1024) void k_plateau_scan(uint32_t *__restrict__ tile_live, size_t ntiles, uint32_t *__restrict__ total_out) {
+    __shared__ uint32_t s_tmp[16 + 1];
+    const size_t per = (ntiles + 1023) / 1024;
+    const size_t b0 = static_cast<size_t>(threadIdx.x) * per;
+    const size_t b1 = b0 + per < ntiles ? b0 + per : ntiles;
+    uint32_t sum = 0;
+    for (size_t b = b0; b < b1; ++b) sum += tile_live[b];
+    uint32_t total;
+    uint32_t run = block_excl_sum<16>(sum, s_tmp, &total);
+    for (size_t b = b0; b < b1; ++b) {
+        const uint32_t v = tile_live[b];
+        tile_live[b] = run;
+        run += v;
+    }
+    if (threadIdx.x == 0) *total_out = total;
+}
+__global__ __launch_bounds__(RR_BLOCK) void k_plateau_compact(const uint32_t *__restrict__ idx, const uint16_t *__restrict__ meta,
+                                                              const uint8_t *__restrict__ sym, const uint32_t *__restrict__ pos,
+                                                              size_t slots, const uint32_t *__restrict__ tile_base,
+                                                              uint32_t *__restrict__ idx_out, uint16_t *__restrict__ meta_out,
+                                                              uint8_t *__restrict__ sym_out, uint32_t *__restrict__ pos_out) {
+    __shared__ uint32_t s_tmp[RR_WAVES + 1];
+    const size_t a0 = static_cast<size_t>(blockIdx.x) * RR_TILE + static_cast<size_t>(threadIdx.x) * RR_IPT;
+    uint32_t v[RR_IPT], c = 0;
+#pragma unroll
+    for (int j = 0; j < RR_IPT; ++j) {
+        v[j] = a0 + j < slots ? idx[a0 + j] : PL_DEAD;
+        c += (v[j] & PL_DEAD_BIT) ? 0u : 1u;
+    }
+    uint32_t o = tile_base[blockIdx.x] + block_excl_sum<RR_WAVES>(c, s_tmp, nullptr);
+#pragma unroll
+    for (int j = 0; j < RR_IPT; ++j) {
+        if (v[j] & PL_DEAD_BIT) continue;
+        idx_out[o] = v[j];
+        meta_out[o] = static_cast<uint16_t>(meta[a0 + j] & (PL_MOVED - 1u));
+        pos_out[o] = pos[a0 + j];
+        if (sym) sym_out[o] = sym[a0 + j];
+        ++o;
+    }
 }
 
 // enqueue the classification of the groups rerank() just produced and read back (active, groups, big slots)
@@ -617,7 +793,7 @@ int classify_and_read(dk_ctx *ctx, size_t max_groups, uint32_t *gstart, uint32_t
     uint32_t *part = ctx->ws_alloc<uint32_t>(ntiles);
     if (!part) return DK_E_NOMEM;
     {
-        LaunchScope ls(ctx, K_RERANK_SCAN, 8.0 * max_groups);
+        LaunchScope ls(ctx, K_BIG_CLASSIFY, 8.0 * max_groups);
         k_big_reduce<<<dim3(ntiles), dim3(256), 0, st>>>(gstart, ctx->d_mail, part);
         k_big_spine<<<dim3(1), dim3(1024), 0, st>>>(part, ntiles, ctx->d_mail, bigstart);
         k_big_apply<<<dim3(ntiles), dim3(256), 0, st>>>(gstart, ctx->d_mail, part, bigstart);
@@ -703,7 +879,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
             DK_HIP(ctx, hipMemsetAsync(table, 0xFF, static_cast<size_t>(table_size) * sizeof(uint64_t), st));
             DK_HIP(ctx, hipMemsetAsync(d_dups, 0, PP_MAX_CAND * sizeof(uint32_t), st));
             {
-                LaunchScope ls(ctx, K_MISC, 16.0 * m);
+                LaunchScope ls(ctx, K_PREFIX_PROBE, 16.0 * m);
                 k_prefix_probe<<<dim3(div_up(m, 256)), dim3(256), 0, st>>>(d_text, n, d_code, bits, spk, m, span, cands, table, table_size - 1,
                                                                           d_dups);
             }
@@ -718,17 +894,26 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
                         ctx->h_mail[303], spk_sort, spk);
         }
     }
-    const bool short_prefix = spk_sort < spk;
-    // BWT on the way (callers that want L, short-prefix path, room for one more byte in the key): see k_pack_keys / FirstBwt
-    const bool carry_bwt = short_prefix && d_bwt && d_origin && bwt_written && bits * spk_sort <= 56;
+    // BWT on the way (BwtCarry): callers that want L.  The key gives up its low byte to the code of the symbol in front of the suffix, so
+    // the initial sort covers at most 56 bits = seven passes instead of eight; nothing is gathered from the text afterwards.
+    // DK_BWT_CARRY=0 (test hook): sort the full key and let the caller gather L from the suffix array.
+    static const bool carry_enabled = [] { const char *e = getenv("DK_BWT_CARRY"); return !(e && e[0] == '0'); }();
+    const bool carry_bwt = carry_enabled && d_bwt && d_origin && bwt_written;
+    const bool short_prefix = spk_sort < spk;  // the probe's verdict: few suffixes will survive the initial sort
+    if (carry_bwt) spk_sort = std::min(spk_sort, 56 / bits);  // (a key merely shortened to make room for the carried byte keeps the rank path)
+    uint8_t *sym = nullptr, *sym_alt = nullptr;
     uint8_t *d_inv = reinterpret_cast<uint8_t *>(ctx->d_mail + 576);
     if (carry_bwt) {
+        sym = ctx->ws_alloc<uint8_t>(n);
+        sym_alt = ctx->ws_alloc<uint8_t>(n);
+        if (!sym || !sym_alt) return DK_E_NOMEM;
         uint8_t inv[256] = {0};
-        for (int sym = 255; sym >= 0; --sym)
-            if (ctx->h_mail[16 + sym]) inv[code[sym]] = static_cast<uint8_t>(sym);
+        for (int c = 255; c >= 0; --c)
+            if (ctx->h_mail[16 + c]) inv[code[c]] = static_cast<uint8_t>(c);
         std::memcpy(ctx->h_mail + 576, inv, 256);
         DK_HIP(ctx, hipMemcpyAsync(d_inv, ctx->h_mail + 576, 256, hipMemcpyHostToDevice, st));
     }
+    const int key_shift = carry_bwt ? 8 : 0;
 
     // 3. initial keys and sort
     {
@@ -736,56 +921,48 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
         k_pack_keys<<<dim3(div_up(n, PK_TILE)), dim3(PK_BLOCK), 0, st>>>(d_text, n, d_code, bits, spk_sort, keys, vals, carry_bwt ? 1 : 0);
     }
     DK_HIP(ctx, hipGetLastError());
-    DK_TRY(sort_pairs(ctx, keys, keys_alt, vals, vals_alt, n, carry_bwt ? 8 : 0, bits * spk_sort + (carry_bwt ? 8 : 0)));
+    DK_TRY(sort_pairs(ctx, keys, keys_alt, vals, vals_alt, n, key_shift, bits * spk_sort + key_shift));
 
     // 4. first rerank (slots are SA positions)
     size_t active = 0, groups = 0, nbig = 0;
     bool have_ranks = true;
     static const bool bucketed = [] { const char *e = getenv("DK_BUCKETED"); return !(e && e[0] == '0'); }();
+    const BwtCarry first_bc{key_shift, carry_bwt ? d_bwt : nullptr, d_inv, d_origin, nullptr, sym};
     if (short_prefix) {
         // few suffixes are expected to survive and they are finished from the text: no rank array unless that fails (step 5b)
-        const FirstBwt fb{carry_bwt ? 8 : 0, carry_bwt ? d_bwt : nullptr, d_inv, d_origin};
-        DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, nullptr, d_sa, vals_alt, pos, gid, gstart, nullptr, false, nullptr, fb));
+        DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, nullptr, d_sa, vals_alt, pos, gid, gstart, nullptr, false, nullptr, first_bc));
         have_ranks = false;
     } else if (bucketed && n >= (1u << 22)) {
         // rank[suffix] = head position for all n suffixes: too random for plain stores (every 4-byte store is a 64-byte line
         // at the HBM) -> the rerank only lists the head positions, the bucketed scatter stores them XCD-locally
         bool need_ranks = true;
-        DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, rank, d_sa, vals_alt, pos, gid, gstart, vals_3, true, &need_ranks));
+        DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, rank, d_sa, vals_alt, pos, gid, gstart, vals_3, true, &need_ranks, first_bc));
         if (need_ranks) DK_TRY(scatter_u32_bucketed(ctx, vals, vals_3, n, n, keys_alt, rank));
     } else {
-        DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, rank, d_sa, vals_alt, pos, gid, gstart, nullptr, true));
+        DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, rank, d_sa, vals_alt, pos, gid, gstart, nullptr, true, nullptr, first_bc));
     }
     DK_TRY(classify_and_read(ctx, n / 2, gstart, bigstart, &active, &groups, &nbig));
     std::swap(vals, vals_alt);  // vals = suffix indices of the active list
-    // the SA positions that are still open: their BWT symbols are gathered at the very end (carry_bwt)
-    uint32_t *open_pos = nullptr;
-    const size_t open_count = active;
-    if (carry_bwt && active > 0) {
-        open_pos = ctx->ws_alloc<uint32_t>(active);
-        if (!open_pos) return DK_E_NOMEM;
-        DK_HIP(ctx, hipMemcpyAsync(open_pos, pos, active * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-    }
 
     uint64_t h = static_cast<uint64_t>(spk_sort);
     if (trace)
-        fprintf(stderr, "[dk] n=%zu sigma=%u bits=%d spk=%d: after init sort active=%zu groups=%zu big=%zu\n", n, sigma, bits, spk_sort,
-                active, groups, nbig);
+        fprintf(stderr, "[dk] n=%zu sigma=%u bits=%d spk=%d%s: after init sort active=%zu groups=%zu big=%zu\n", n, sigma, bits, spk_sort,
+                carry_bwt ? " +prev" : "", active, groups, nbig);
 
-    // one round: secondary keys (ranks h further on, or the next tsym symbols of the text) -> every group sorted inside its own
-    // slot range (small groups in LDS, big ones through the global sort) -> rerank
+    // one general round: secondary keys (ranks h further on, or the next tsym symbols of the text) -> every group sorted inside its
+    // own slot range (small groups in LDS, big ones through the global sort) -> rerank
     auto run_round = [&](int kbits, int tsym) -> int {
         const int gbits = static_cast<int>(ceil_log2_u64(groups));
         const uint32_t h_eff = static_cast<uint32_t>(std::min<uint64_t>(h, n));
         const TextSource ts{d_text, d_code, bits, tsym};
         {
-            LaunchScope ls(ctx, K_BUILD_KEYS, 8.0 * active + 4.0 * active + 12.0 * active);
+            LaunchScope ls(ctx, K_ROUND_LOCAL, 8.0 * active + 4.0 * active + 12.0 * active);
             if (tsym > 0)
                 k_round_local<true><<<dim3(div_up(active, LS_TILE)), dim3(LS_BLOCK), 0, st>>>(
-                    vals, gid, gstart, bigstart, rank, static_cast<uint32_t>(n), h_eff, kbits, active, keys, vals_alt, keys_alt, vals_3, ts);
+                    vals, gid, gstart, bigstart, rank, static_cast<uint32_t>(n), h_eff, kbits, active, keys, vals_alt, keys_alt, vals_3, ts, sym, sym_alt);
             else
                 k_round_local<false><<<dim3(div_up(active, LS_TILE)), dim3(LS_BLOCK), 0, st>>>(
-                    vals, gid, gstart, bigstart, rank, static_cast<uint32_t>(n), h_eff, kbits, active, keys, vals_alt, keys_alt, vals_3, ts);
+                    vals, gid, gstart, bigstart, rank, static_cast<uint32_t>(n), h_eff, kbits, active, keys, vals_alt, keys_alt, vals_3, ts, sym, sym_alt);
         }
         DK_HIP(ctx, hipGetLastError());
         if (nbig > 0) {
@@ -793,14 +970,17 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
             uint32_t *bv = vals_3, *bv_alt = vals_4;
             DK_TRY(sort_pairs(ctx, bk, bk_alt, bv, bv_alt, nbig, 0, kbits + gbits));
             {
-                LaunchScope ls(ctx, K_MISC, 24.0 * nbig);
-                k_big_back<<<dim3(div_up(nbig, 256)), dim3(256), 0, st>>>(bk, bv, nbig, kbits, gstart, bigstart, keys, vals_alt);
+                LaunchScope ls(ctx, K_BIG_BACK, 24.0 * nbig);
+                k_big_back<<<dim3(div_up(nbig, 256)), dim3(256), 0, st>>>(bk, bv, nbig, kbits, gstart, bigstart, keys, vals_alt, d_text,
+                                                                          static_cast<uint32_t>(n), carry_bwt ? sym_alt : nullptr);
             }
             DK_HIP(ctx, hipGetLastError());
         }
-        // keys / vals_alt now hold every group sorted by its secondary key in its own slot range
+        // keys / vals_alt (/ sym_alt) now hold every group sorted by its secondary key in its own slot range
         size_t next_active = 0, next_groups = 0, next_big = 0;
-        DK_TRY(rerank(ctx, keys, vals_alt, pos, active, kbits, have_ranks ? rank : nullptr, d_sa, vals, pos_alt, gid_alt, gstart));
+        const BwtCarry bc{0, carry_bwt ? d_bwt : nullptr, nullptr, d_origin, sym_alt, sym};
+        DK_TRY(rerank(ctx, keys, vals_alt, pos, active, kbits, have_ranks ? rank : nullptr, d_sa, vals, pos_alt, gid_alt, gstart, nullptr, false,
+                      nullptr, bc));
         DK_TRY(classify_and_read(ctx, active / 2, gstart, bigstart, &next_active, &next_groups, &next_big, nbig == 0));
         std::swap(pos, pos_alt);
         std::swap(gid, gid_alt);
@@ -825,33 +1005,108 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     // 5b. survivors beyond that (long repeats): build the rank array the doubling rounds need
     if (active > 0 && !have_ranks) {
         {
-            LaunchScope ls(ctx, K_MISC, 12.0 * active);
+            LaunchScope ls(ctx, K_PLACE_ACTIVE, 12.0 * active);
             k_place_active<<<dim3(div_up(active, 256)), dim3(256), 0, st>>>(vals, pos, active, d_sa);
         }
         DK_TRY(scatter_u32_bucketed(ctx, d_sa, nullptr, n, n, keys_alt, rank));  // rank[SA[p]] = p
         {
-            LaunchScope ls(ctx, K_MISC, 16.0 * active);
+            LaunchScope ls(ctx, K_PLACE_ACTIVE, 16.0 * active);
             k_rank_active<<<dim3(div_up(active, 256)), dim3(256), 0, st>>>(vals, pos, gid, gstart, active, rank);
         }
         DK_HIP(ctx, hipGetLastError());
         have_ranks = true;
     }
 
-    // 5c. doubling rounds
-    while (active > 0) {
+    // 5c. doubling rounds: the general form while big groups exist, ...
+    static const bool plateau_enabled = [] { const char *e = getenv("DK_PLATEAU"); return !(e && e[0] == '0'); }();
+    while (active > 0 && (nbig > 0 || !plateau_enabled)) {
         if (ctx->stats.rounds > 44) return ctx->fail(DK_E_INTERNAL, "suffix_array: no convergence after 44 rounds");
         const uint32_t h_eff = static_cast<uint32_t>(std::min<uint64_t>(h, n));
         DK_TRY(run_round(static_cast<int>(ceil_log2_u64(static_cast<uint64_t>(n) + h_eff)), 0));
         h *= 2;
     }
-    if (carry_bwt) {
-        if (open_count > 0) {
-            LaunchScope ls(ctx, K_BWT_GATHER, 10.0 * open_count);
-            k_bwt_gather_list<<<dim3(div_up(open_count, 256)), dim3(256), 0, st>>>(d_text, d_sa, n, open_pos, open_count, d_bwt, d_origin);
+    // ... then in place (k_plateau_sort): one sort kernel + one rank kernel per round, the live count read back one round late
+    if (active > 0) {
+        size_t slots = active;
+        uint32_t *idx_a = vals, *idx_b = vals_alt;
+        uint16_t *meta_a = reinterpret_cast<uint16_t *>(gid), *meta_b = reinterpret_cast<uint16_t *>(gid_alt);
+        uint8_t *sym_a = sym, *sym_b = sym_alt;
+        uint32_t *d_live = ctx->d_mail + 700, *h_live = ctx->h_mail + 700;  // ring of 8 counters
+        {
+            LaunchScope ls(ctx, K_PLATEAU_RANKS, 14.0 * slots);
+            k_to_inplace<<<dim3(div_up(slots, 256)), dim3(256), 0, st>>>(gid, gstart, slots, meta_b);
         }
-        DK_HIP(ctx, hipGetLastError());
-        *bwt_written = true;
+        std::swap(meta_a, meta_b);  // gid was read, gid_alt written
+        unsigned launched = 0, read = 0;
+        size_t live = active;
+        auto launch_round = [&]() -> int {
+            const uint32_t h_eff = static_cast<uint32_t>(std::min<uint64_t>(h, n));
+            uint32_t *cnt = d_live + (launched & 7u);
+            DK_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t), st));
+            {
+                LaunchScope ls(ctx, K_PLATEAU_SORT, 6.0 * slots + 4.0 * live + 10.0 * live);
+                k_plateau_sort<<<dim3(div_up(slots, LS_TILE)), dim3(LS_BLOCK), 0, st>>>(idx_a, meta_a, sym_a, pos, rank, static_cast<uint32_t>(n), h_eff,
+                                                                                      slots, idx_b, meta_b, sym_b, d_sa, d_bwt, d_origin, cnt);
+            }
+            {
+                LaunchScope ls(ctx, K_PLATEAU_RANKS, 6.0 * slots);
+                k_plateau_ranks<<<dim3(div_up(slots, 256)), dim3(256), 0, st>>>(idx_b, meta_b, pos, slots, rank);
+            }
+            DK_HIP(ctx, hipGetLastError());
+            DK_HIP(ctx, hipMemcpyAsync(h_live + (launched & 7u), cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            DK_HIP(ctx, hipEventRecord(ctx->round_ev[launched & 7u], st));
+            std::swap(idx_a, idx_b);
+            std::swap(meta_a, meta_b);
+            std::swap(sym_a, sym_b);
+            h = std::min<uint64_t>(h * 2, static_cast<uint64_t>(n) * 2);
+            ++launched;
+            return DK_OK;
+        };
+        auto read_round = [&]() -> int {  // the oldest round in flight: how many slots did it leave alive?
+            DK_HIP(ctx, hipEventSynchronize(ctx->round_ev[read & 7u]));
+            const size_t before = live;
+            live = h_live[read & 7u];
+            ++read;
+            ctx->stats.rounds += 1;
+            if (trace) fprintf(stderr, "[dk] round %u (in place) slots=%zu live %zu -> %zu\n", ctx->stats.rounds - 1, slots, before, live);
+            return DK_OK;
+        };
+        for (;;) {
+            if (ctx->stats.rounds > 44) return ctx->fail(DK_E_INTERNAL, "suffix_array: no convergence after 44 rounds");
+            DK_TRY(launch_round());
+            if (launched - read < 2) continue;  // keep one round ahead of the host
+            DK_TRY(read_round());
+            if (live == 0) break;  // the round launched since ran over dead slots only
+            if (live * 4 <= slots && slots >= (1u << 16)) {
+                // mostly dead slots: drain the round in flight, then compact (live slots keep their order: groups stay contiguous)
+                DK_TRY(read_round());
+                if (live == 0) break;
+                const size_t mark2 = ctx->ws_mark();
+                const size_t ntiles = div_up(slots, RR_TILE);
+                uint32_t *tile_live = ctx->ws_alloc<uint32_t>(ntiles);
+                if (!tile_live) return DK_E_NOMEM;
+                {
+                    LaunchScope ls(ctx, K_PLATEAU_RANKS, 4.0 * slots + 22.0 * live);
+                    k_plateau_count<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(idx_a, slots, tile_live);
+                    k_plateau_scan<<<dim3(1), dim3(1024), 0, st>>>(tile_live, ntiles, d_live);
+                    k_plateau_compact<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(idx_a, meta_a, sym_a, pos, slots, tile_live, idx_b, meta_b, sym_b, pos_alt);
+                }
+                DK_HIP(ctx, hipGetLastError());
+                DK_HIP(ctx, hipMemcpyAsync(h_live, d_live, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                DK_HIP(ctx, hipStreamSynchronize(st));
+                if (h_live[0] != live) return ctx->fail(DK_E_INTERNAL, "suffix_array: live count %u after compaction, expected %zu", h_live[0], live);
+                ctx->ws_release(mark2);
+                std::swap(idx_a, idx_b);
+                std::swap(meta_a, meta_b);
+                std::swap(sym_a, sym_b);
+                std::swap(pos, pos_alt);
+                slots = live;
+                launched = read = 0;
+            }
+        }
+        active = 0;
     }
+    if (carry_bwt) *bwt_written = true;
     ctx->ws_release(mark);
     DK_TRY(sort_check_error(ctx));
     return DK_OK;

@@ -137,7 +137,7 @@ int dk_stream_decode(int model_id, const uint8_t *in, size_t in_len, size_t n, u
                      int *single_symbol, size_t *consumed /* may be NULL: bytes of `in` read = the length the encoder wrote */);
 
 /* ---- measurement ------------------------------------------------------------------------------------------ */
-#define DK_NUM_KERNEL_SLOTS 24
+#define DK_NUM_KERNEL_SLOTS 32
 typedef struct dk_stats {
     /* wall-clock stage times of the last block call on this context, milliseconds */
     double ms_h2d, ms_sa, ms_bwt, ms_dc, ms_d2h, ms_entropy, ms_ibwt, ms_total;

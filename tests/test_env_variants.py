@@ -1,6 +1,7 @@
 """Alternative code paths selected by environment variables (read once per process, hence subprocesses):
 DK_ENTROPY_THREADS=2|4 (models | coder on two host threads, the four-stage pipeline of the dark model), DK_SORT=onesweep (single-kernel look-back radix passes),
-DK_BUCKETED=0 / DK_XCD=0 (plain rank scatter / plain tile order).  Every variant must give the same bytes."""
+DK_BUCKETED=0 / DK_XCD=0 (plain rank scatter / plain tile order), DK_PLATEAU=0 (general doubling rounds only, no in-place rounds),
+DK_BWT_CARRY=0 (L gathered from the suffix array instead of riding with the suffixes).  Every variant must give the same bytes."""
 import os
 import subprocess
 import sys
@@ -66,7 +67,11 @@ with dark_amd.Context(6 << 20) as ctx:
     assert (v2 == vals[np.argsort(keys, kind="stable")]).all()
     for t in (datagen.wiki_like(4500000, 7), np.frombuffer(b"ab" * 50000, np.uint8), rng.integers(0, 4, size=300000, dtype=np.uint8)):
         t = np.ascontiguousarray(t)
-        assert (ctx.suffix_array(t) == orc.sa_sais(t)).all()
+        want = orc.sa_sais(t)
+        assert (ctx.suffix_array(t) == want).all()
+        bwt, origin = ctx.bwt_forward(t)      # BwtCarry (the symbol in front rides with the suffix) or the gather, by variant
+        wb, wo = orc.bwt_forward(t, want)
+        assert origin == wo and (bwt == wb).all()
 print("ok")
 """
 
@@ -132,7 +137,8 @@ def test_entropy_error_paths_return_codes(threads):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"DK_SORT": "onesweep"}, {"DK_SORT": "chunked"}, {"DK_BUCKETED": "0"}, {"DK_XCD": "0"}])
+@pytest.mark.parametrize("env", [{"DK_SORT": "onesweep"}, {"DK_SORT": "chunked"}, {"DK_BUCKETED": "0"}, {"DK_XCD": "0"},
+                                 {"DK_PLATEAU": "0"}, {"DK_BWT_CARRY": "0"}, {"DK_PLATEAU": "0", "DK_BWT_CARRY": "0"}])
 def test_gpu_variants_match_oracle(env):
     _run(GPU_SNIPPET, env)
 
