@@ -179,22 +179,32 @@ struct RerankAgg { uint32_t surv, heads, last_head, pad; };
 // Per-slot flags, computed with lane-contiguous (coalesced) accesses and parked in LDS as one byte per slot:
 //   bit 0 head : the key differs from its predecessor (slot 0 is a head)
 //   bit 1 surv : the slot's group has more than one member
-//   bit 2 oldh : the slot is a head AND already headed its group before this round (gshift >= 0: the group id sits above
-//                bit gshift of the key); members of such a group keep their rank, so the rank scatter is skipped
+//   bit 2 oldh : the slot is a head AND already headed its group before this round (gid_in: the group every slot belonged to before
+//                the round -- members only move inside their group's slot range, so that is a property of the slot); members of
+//                such a group keep their rank, so the rank scatter is skipped
+// The keys of one old group are compared among themselves only: across a group boundary a new group starts whatever the keys say,
+// so a round's key need not repeat the group id above its secondary key.
 constexpr uint32_t F_HEAD = 1, F_SURV = 2, F_OLDH = 4;
 
-__device__ __forceinline__ uint32_t slot_flag_bits(uint64_t prev, uint64_t cur, uint64_t next, size_t a, size_t count, int gshift) {
+__device__ __forceinline__ uint32_t slot_flag_bits(uint64_t prev, uint64_t cur, uint64_t next, size_t a, size_t count,
+                                                   const uint32_t *__restrict__ gid_in) {
     if (a >= count) return 0;
-    const bool head = a == 0 || cur != prev;
-    const bool next_head = a + 1 >= count || next != cur;
-    const bool oldh = head && gshift >= 0 && (a == 0 || (cur >> gshift) != (prev >> gshift));
+    bool old_here = a == 0, old_next = a + 1 >= count;
+    if (gid_in) {
+        const uint32_t g = gid_in[a];
+        old_here = old_here || gid_in[a - 1] != g;
+        old_next = old_next || gid_in[a + 1] != g;
+    }
+    const bool head = old_here || cur != prev;
+    const bool next_head = old_next || next != cur;
+    const bool oldh = head && gid_in && old_here;
     return (head ? F_HEAD : 0u) | (!(head && next_head) ? F_SURV : 0u) | (oldh ? F_OLDH : 0u);
 }
 
 // stage keys[b0-1 .. b0+RR_TILE] into s_key[0 .. RR_TILE+1] (coalesced), then the flag bytes of the tile into s_flag
 // cmp_shift: low bits of the keys that take no part in the comparison (the previous-symbol byte of the short-prefix path); they are
 // parked in s_low (one byte per slot, s_low[o] belongs to slot b0 + o) when that is given.
-__device__ __forceinline__ void stage_flags(const uint64_t *__restrict__ keys, size_t count, size_t b0, int gshift,
+__device__ __forceinline__ void stage_flags(const uint64_t *__restrict__ keys, size_t count, size_t b0, const uint32_t *__restrict__ gid_in,
                                             uint64_t *s_key, uint8_t *s_flag, int cmp_shift = 0, uint8_t *s_low = nullptr) {
     const int tid = threadIdx.x;
     for (int o = tid; o < RR_TILE + 2; o += RR_BLOCK) {
@@ -207,7 +217,7 @@ __device__ __forceinline__ void stage_flags(const uint64_t *__restrict__ keys, s
 #pragma unroll
     for (int k = 0; k < RR_IPT; ++k) {
         const int o = k * RR_BLOCK + tid;
-        s_flag[o] = static_cast<uint8_t>(slot_flag_bits(s_key[o], s_key[o + 1], s_key[o + 2], b0 + o, count, gshift));
+        s_flag[o] = static_cast<uint8_t>(slot_flag_bits(s_key[o], s_key[o + 1], s_key[o + 2], b0 + o, count, gid_in));
     }
     __syncthreads();
 }
@@ -225,13 +235,13 @@ __device__ __forceinline__ void thread_summary(uint64_t fl, size_t a0, uint32_t 
     }
 }
 
-__global__ __launch_bounds__(RR_BLOCK) void k_rerank_reduce(const uint64_t *__restrict__ keys, size_t count, int gshift,
+__global__ __launch_bounds__(RR_BLOCK) void k_rerank_reduce(const uint64_t *__restrict__ keys, size_t count, const uint32_t *__restrict__ gid_in,
                                                              RerankAgg *__restrict__ agg, int cmp_shift) {
     __shared__ uint64_t s_key[RR_TILE + 2];
     __shared__ __attribute__((aligned(8))) uint8_t s_flag[RR_TILE];
     __shared__ uint32_t s_red[3][RR_WAVES];
     const size_t b0 = static_cast<size_t>(blockIdx.x) * RR_TILE;
-    stage_flags(keys, count, b0, gshift, s_key, s_flag, cmp_shift);
+    stage_flags(keys, count, b0, gid_in, s_key, s_flag, cmp_shift);
     const size_t a0 = b0 + static_cast<size_t>(threadIdx.x) * RR_IPT;
     uint32_t ns, nh, lh;
     thread_summary(*reinterpret_cast<const uint64_t *>(s_flag + threadIdx.x * RR_IPT), a0, ns, nh, lh);
@@ -300,7 +310,7 @@ constexpr BwtCarry NO_CARRY{0, nullptr, nullptr, nullptr, nullptr, nullptr};
 // FIRST = (pos_in == nullptr): no position array to stage, 8 KiB of LDS less -> more workgroups per CU for the largest launch
 template <bool FIRST>
 __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx,
-                                                            const uint32_t *__restrict__ pos_in, size_t count, int gshift,
+                                                            const uint32_t *__restrict__ pos_in, size_t count, const uint32_t *__restrict__ gid_in,
                                                             const RerankAgg *__restrict__ agg, uint32_t *__restrict__ rank,
                                                             uint32_t *__restrict__ sa, uint32_t *__restrict__ out_idx,
                                                             uint32_t *__restrict__ out_pos, uint32_t *__restrict__ out_gid,
@@ -324,7 +334,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
         }
     }
     // ends with a barrier: s_idx / s_pos (/ s_low) are visible, s_key is free
-    stage_flags(keys, count, b0, gshift, s_key, s_flag, FIRST ? bc.cmp_shift : 0, (FIRST && bc.bwt) ? s_low : nullptr);
+    stage_flags(keys, count, b0, gid_in, s_key, s_flag, FIRST ? bc.cmp_shift : 0, (FIRST && bc.bwt) ? s_low : nullptr);
     const size_t a0 = b0 + static_cast<size_t>(tid) * RR_IPT;
     const uint64_t fl = *reinterpret_cast<const uint64_t *>(s_flag + tid * RR_IPT);
     uint64_t sym8 = 0;  // bc.bwt: the symbols in front of this thread's eight suffixes
@@ -416,7 +426,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
 // probe_active (first rerank only): read the number of surviving slots back after the reduce/scan phases; when it is zero the
 // initial sort already separated every suffix (random bytes, small alphabets with long keys) and nobody will ever read the
 // rank array, so the apply phase only writes SA.
-int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_t *pos_in, size_t count, int gshift, uint32_t *rank,
+int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_t *pos_in, size_t count, const uint32_t *gid_in, uint32_t *rank,
            uint32_t *sa, uint32_t *out_idx, uint32_t *out_pos, uint32_t *out_gid, uint32_t *gstart, uint32_t *headpos_out = nullptr,
            bool probe_active = false, bool *ranks_written = nullptr, BwtCarry fb = NO_CARRY) {
     const size_t ntiles = div_up(count, RR_TILE);
@@ -426,7 +436,7 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
     hipStream_t st = ctx->stream;
     {
         LaunchScope ls(ctx, K_RERANK_REDUCE, 8.0 * count);
-        k_rerank_reduce<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, count, gshift, agg, pos_in ? 0 : fb.cmp_shift);
+        k_rerank_reduce<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, count, gid_in, agg, pos_in ? 0 : fb.cmp_shift);
     }
     {
         LaunchScope ls(ctx, K_RERANK_SCAN, 32.0 * ntiles);
@@ -445,9 +455,9 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
     {
         LaunchScope ls(ctx, K_RERANK_APPLY, 8.0 * count + 4.0 * count + 4.0 * count + 12.0 * count);
         if (pos_in)
-            k_rerank_apply<false><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gshift, agg, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out, fb);
+            k_rerank_apply<false><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gid_in, agg, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out, fb);
         else
-            k_rerank_apply<true><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gshift, agg, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out, fb);
+            k_rerank_apply<true><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gid_in, agg, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out, fb);
     }
     DK_HIP(ctx, hipGetLastError());
     ctx->ws_release(mark);
@@ -457,7 +467,7 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
 // ---- big / small classification of the groups of the next round ---------------------------------------------------
 // A group of more than LS_MAX members goes through the global radix sort; bigstart[g] = number of slots in big groups
 // before group g (exclusive scan of the big sizes), bigstart[groups] = total -> mail[2].
-constexpr int LS_MAX = 64;
+constexpr int LS_MAX = 256;
 constexpr int BG_IPT = 16;
 constexpr int BG_TILE = 256 * BG_IPT;
 
@@ -535,12 +545,17 @@ __device__ __forceinline__ uint32_t rank2_of(const uint32_t *__restrict__ rank, 
 // text after the h already sorted ones, packed like the initial keys (64-bit secondary keys in LDS).
 struct TextSource { const uint8_t *text; const uint8_t *code; int bits; int tsym; };
 
+// Small groups: key_out = the secondary key alone (the rerank compares keys inside an old group only).  Big groups: the global sort
+// must keep every group in its range of the big list, so its key is (offset of the group in the big list) above the secondary key,
+// cut to its leading `kb` bits when both do not fit 64 bits (text rounds: fewer symbols for the big groups); bslot remembers which
+// slot every position of the big list came from.
 template <bool TEXT>
 __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__restrict__ act_idx, const uint32_t *__restrict__ act_gid,
                                                           const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ bigstart,
-                                                          const uint32_t *__restrict__ rank, uint32_t n, uint32_t h, int kbits,
+                                                          const uint32_t *__restrict__ rank, uint32_t n, uint32_t h, int kbits, int kb,
                                                           size_t count, uint64_t *__restrict__ key_out, uint32_t *__restrict__ idx_out,
-                                                          uint64_t *__restrict__ bkeys, uint32_t *__restrict__ bidx, TextSource ts,
+                                                          uint64_t *__restrict__ bkeys, uint32_t *__restrict__ bidx,
+                                                          uint32_t *__restrict__ bslot, TextSource ts,
                                                           const uint8_t *__restrict__ sym_in, uint8_t *__restrict__ sym_out) {
     using R2 = typename std::conditional<TEXT, uint64_t, uint32_t>::type;
     __shared__ R2 s_r2[LS_TILE + 2 * LS_MAX];
@@ -561,9 +576,9 @@ __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__rest
             s_r2[LS_MAX + k * LS_BLOCK + tid] = my_r2[k];
         }
     }
-    if (tid < 2 * LS_MAX) {  // halo: LS_MAX slots before the tile, LS_MAX after
-        const bool left = tid < LS_MAX;
-        const size_t off = left ? static_cast<size_t>(tid) : static_cast<size_t>(LS_TILE) + LS_MAX + (tid - LS_MAX);
+    for (int t = tid; t < 2 * LS_MAX; t += LS_BLOCK) {  // halo: LS_MAX slots before the tile, LS_MAX after
+        const bool left = t < LS_MAX;
+        const size_t off = left ? static_cast<size_t>(t) : static_cast<size_t>(LS_TILE) + LS_MAX + (t - LS_MAX);
         // slot index = b0 - LS_MAX + off; guard both ends of the list
         if (b0 + off >= static_cast<size_t>(LS_MAX) && b0 + off - LS_MAX < count) {
             const size_t a = b0 + off - LS_MAX;
@@ -577,7 +592,6 @@ __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__rest
         if (a >= count) continue;
         const uint32_t g = act_gid[a];
         const uint32_t gs = gstart[g], ge = gstart[g + 1];
-        const uint64_t key = (static_cast<uint64_t>(g) << kbits) | my_r2[k];
         if (ge - gs <= static_cast<uint32_t>(LS_MAX)) {
             const R2 mine = my_r2[k];
             // LDS index of slot b is b - (b0 - LS_MAX) = b + LS_MAX - b0 (never negative: gs >= a - LS_MAX + 1)
@@ -587,30 +601,31 @@ __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__rest
                 const R2 v = s_r2[b + base];
                 before += (v < mine) || (v == mine && b < static_cast<uint32_t>(a));
             }
-            key_out[gs + before] = key;
+            key_out[gs + before] = static_cast<uint64_t>(mine);
             idx_out[gs + before] = my_idx[k];
             if (sym_in) sym_out[gs + before] = sym_in[a];  // the symbol in front of the suffix travels with it (BwtCarry)
         } else {
-            const uint32_t bo = bigstart[g] + (static_cast<uint32_t>(a) - gs);
-            bkeys[bo] = key;
+            const uint32_t bs = bigstart[g];
+            const uint32_t bo = bs + (static_cast<uint32_t>(a) - gs);
+            bkeys[bo] = (static_cast<uint64_t>(bs) << kb) | (static_cast<uint64_t>(my_r2[k]) >> (kbits - kb));
             bidx[bo] = my_idx[k];
+            bslot[bo] = static_cast<uint32_t>(a);
         }
     }
 }
 
-// sorted big list -> back into the slots of the big groups (a sorted element stays inside its group's slot range).  sym_out (BwtCarry):
-// the few members of big groups fetch the symbol in front of their suffix from the text again instead of dragging it through the sort.
-__global__ __launch_bounds__(256) void k_big_back(const uint64_t *__restrict__ bkeys, const uint32_t *__restrict__ bidx, size_t nbig,
-                                                   int kbits, const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ bigstart,
-                                                   uint64_t *__restrict__ key_out, uint32_t *__restrict__ idx_out,
-                                                   const uint8_t *__restrict__ text, uint32_t n, uint8_t *__restrict__ sym_out) {
+// sorted big list -> back into the slots of the big groups: a sorted element stays inside its group's range of the big list, and
+// position q of that list came from slot bslot[q].  sym_out (BwtCarry): the few members of big groups fetch the symbol in front of
+// their suffix from the text again instead of dragging it through the sort.
+__global__ __launch_bounds__(256) void k_big_back(const uint64_t *__restrict__ bkeys, const uint32_t *__restrict__ bidx,
+                                                   const uint32_t *__restrict__ bslot, size_t nbig, uint64_t *__restrict__ key_out,
+                                                   uint32_t *__restrict__ idx_out, const uint8_t *__restrict__ text, uint32_t n,
+                                                   uint8_t *__restrict__ sym_out) {
     const size_t bo = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (bo >= nbig) return;
-    const uint64_t key = bkeys[bo];
-    const uint32_t g = static_cast<uint32_t>(key >> kbits);
-    const uint32_t a = gstart[g] + (static_cast<uint32_t>(bo) - bigstart[g]);
+    const uint32_t a = bslot[bo];
     const uint32_t suffix = bidx[bo];
-    key_out[a] = key;
+    key_out[a] = bkeys[bo];
     idx_out[a] = suffix;
     if (sym_out) sym_out[a] = text[suffix ? suffix - 1 : n - 1];
 }
@@ -619,7 +634,7 @@ __global__ __launch_bounds__(256) void k_big_back(const uint64_t *__restrict__ b
 // Once a round ends without a big group there will never be one again (groups only split), and what is left are typically the
 // suffixes inside long repeats: the list shrinks slowly for log2(repeat length) rounds.  These rounds run on an IN-PLACE list:
 //   idx[a]   suffix in slot a; bit 31 set = the slot is dead (its suffix is final)
-//   meta[a]  offset of the slot inside its group (6 bits) | group size - 1 (6 bits) << 6 | PL_MOVED << 12
+//   meta[a]  offset of the slot inside its group (9 bits) | (group size - 1) << 9 | PL_MOVED
 //   pos[a]   SA position of slot a (never changes: members move only inside their group's slot range)
 // One kernel per round sorts every group inside LDS by the rank of the suffix h further on and writes each member to its place
 // (ping-pong idx / meta / sym): its new group is the run of members with the same secondary rank.  No compaction, no global scan,
@@ -627,21 +642,21 @@ __global__ __launch_bounds__(256) void k_big_back(const uint64_t *__restrict__ b
 // them inside the first would let another workgroup see the new rank of one suffix and the old rank of its group mate -- an order
 // that may contradict both the h-order and the 2h-order.
 constexpr uint32_t PL_DEAD = 0xFFFFFFFFu, PL_DEAD_BIT = 0x80000000u;
-constexpr uint32_t PL_MOVED = 1u << 12;  // the slot's group got a new head this round: its members' ranks change
+constexpr uint32_t PL_MOVED = 1u << 18, PL_OFF_MASK = 511u;  // the slot's group got a new head this round: its members' ranks change
 
 __global__ __launch_bounds__(256) void k_to_inplace(const uint32_t *__restrict__ gid, const uint32_t *__restrict__ gstart, size_t count,
-                                                     uint16_t *__restrict__ meta) {
+                                                     uint32_t *__restrict__ meta) {
     const size_t a = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (a >= count) return;
     const uint32_t g = gid[a];
     const uint32_t gs = gstart[g], ge = gstart[g + 1];
-    meta[a] = static_cast<uint16_t>((static_cast<uint32_t>(a) - gs) | ((ge - gs - 1u) << 6));
+    meta[a] = (static_cast<uint32_t>(a) - gs) | ((ge - gs - 1u) << 9);
 }
 
-__global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__restrict__ idx_in, const uint16_t *__restrict__ meta_in,
+__global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__restrict__ idx_in, const uint32_t *__restrict__ meta_in,
                                                            const uint8_t *__restrict__ sym_in, const uint32_t *__restrict__ pos,
                                                            const uint32_t *__restrict__ rank, uint32_t n, uint32_t h, size_t slots,
-                                                           uint32_t *__restrict__ idx_out, uint16_t *__restrict__ meta_out,
+                                                           uint32_t *__restrict__ idx_out, uint32_t *__restrict__ meta_out,
                                                            uint8_t *__restrict__ sym_out, uint32_t *__restrict__ sa,
                                                            uint8_t *__restrict__ bwt, uint32_t *__restrict__ origin,
                                                            uint32_t *__restrict__ live) {
@@ -657,9 +672,9 @@ __global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__res
         my_r2[k] = (my_idx[k] & PL_DEAD_BIT) ? 0u : rank2_of(rank, my_idx[k], n, h);
         s_r2[LS_MAX + k * LS_BLOCK + tid] = my_r2[k];
     }
-    if (tid < 2 * LS_MAX) {  // halo: LS_MAX slots before the tile, LS_MAX after
-        const bool left = tid < LS_MAX;
-        const size_t off = left ? static_cast<size_t>(tid) : static_cast<size_t>(LS_TILE) + LS_MAX + (tid - LS_MAX);
+    for (int t = tid; t < 2 * LS_MAX; t += LS_BLOCK) {  // halo: LS_MAX slots before the tile, LS_MAX after
+        const bool left = t < LS_MAX;
+        const size_t off = left ? static_cast<size_t>(t) : static_cast<size_t>(LS_TILE) + LS_MAX + (t - LS_MAX);
         if (b0 + off >= static_cast<size_t>(LS_MAX) && b0 + off - LS_MAX < slots) {
             const uint32_t v = idx_in[b0 + off - LS_MAX];
             s_r2[off] = (v & PL_DEAD_BIT) ? 0u : rank2_of(rank, v, n, h);
@@ -673,7 +688,7 @@ __global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__res
         if (a >= slots) continue;
         if (my_idx[k] & PL_DEAD_BIT) { idx_out[a] = PL_DEAD; continue; }  // a dead slot is never inside a live group's range
         const uint32_t m = meta_in[a];
-        const uint32_t gs = static_cast<uint32_t>(a) - (m & 63u), ge = gs + ((m >> 6) & 63u) + 1u;
+        const uint32_t gs = static_cast<uint32_t>(a) - (m & PL_OFF_MASK), ge = gs + ((m >> 9) & PL_OFF_MASK) + 1u;
         const uint32_t mine = my_r2[k];
         const uint32_t base = static_cast<uint32_t>(LS_MAX) - static_cast<uint32_t>(b0);  // LDS index of slot b = b + base (mod 2^32)
         uint32_t less = 0, eq_before = 0, eq = 0;
@@ -685,7 +700,7 @@ __global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__res
         }
         const uint32_t dest = gs + less + eq_before;
         const uint32_t moved = less ? PL_MOVED : 0u;  // new head slot gs + less: the rank becomes pos[gs + less]
-        meta_out[dest] = static_cast<uint16_t>(eq_before | ((eq - 1u) << 6) | moved);
+        meta_out[dest] = eq_before | ((eq - 1u) << 9) | moved;
         if (eq == 1) {  // alone in its new group: final
             const uint32_t p = pos[dest];
             sa[p] = my_idx[k];
@@ -708,14 +723,14 @@ __global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__res
 }
 
 // the rank updates of the round k_plateau_sort just ran: members of a group with a new head get that head's SA position
-__global__ __launch_bounds__(256) void k_plateau_ranks(const uint32_t *__restrict__ idx, const uint16_t *__restrict__ meta,
+__global__ __launch_bounds__(256) void k_plateau_ranks(const uint32_t *__restrict__ idx, const uint32_t *__restrict__ meta,
                                                         const uint32_t *__restrict__ pos, size_t slots, uint32_t *__restrict__ rank) {
     const size_t a = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (a >= slots) return;
     const uint32_t v = idx[a];
     if (v == PL_DEAD) return;
     const uint32_t m = meta[a];
-    if (m & PL_MOVED) rank[v & ~PL_DEAD_BIT] = pos[a - (m & 63u)];
+    if (m & PL_MOVED) rank[v & ~PL_DEAD_BIT] = pos[a - (m & PL_OFF_MASK)];
 }
 
 // compaction of the in-place list (when most of its slots are dead): live slots keep their order, so groups stay contiguous
@@ -749,10 +764,10 @@ __global__ __launch_bounds__(1024) void k_plateau_scan(uint32_t *__restrict__ ti
     }
     if (threadIdx.x == 0) *total_out = total;
 }
-__global__ __launch_bounds__(RR_BLOCK) void k_plateau_compact(const uint32_t *__restrict__ idx, const uint16_t *__restrict__ meta,
+__global__ __launch_bounds__(RR_BLOCK) void k_plateau_compact(const uint32_t *__restrict__ idx, const uint32_t *__restrict__ meta,
                                                               const uint8_t *__restrict__ sym, const uint32_t *__restrict__ pos,
                                                               size_t slots, const uint32_t *__restrict__ tile_base,
-                                                              uint32_t *__restrict__ idx_out, uint16_t *__restrict__ meta_out,
+                                                              uint32_t *__restrict__ idx_out, uint32_t *__restrict__ meta_out,
                                                               uint8_t *__restrict__ sym_out, uint32_t *__restrict__ pos_out) {
     __shared__ uint32_t s_tmp[RR_WAVES + 1];
     const size_t a0 = static_cast<size_t>(blockIdx.x) * RR_TILE + static_cast<size_t>(threadIdx.x) * RR_IPT;
@@ -767,7 +782,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_plateau_compact(const uint32_t *__
     for (int j = 0; j < RR_IPT; ++j) {
         if (v[j] & PL_DEAD_BIT) continue;
         idx_out[o] = v[j];
-        meta_out[o] = static_cast<uint16_t>(meta[a0 + j] & (PL_MOVED - 1u));
+        meta_out[o] = meta[a0 + j] & (PL_MOVED - 1u);
         pos_out[o] = pos[a0 + j];
         if (sym) sym_out[o] = sym[a0 + j];
         ++o;
@@ -923,23 +938,27 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     DK_HIP(ctx, hipGetLastError());
     DK_TRY(sort_pairs(ctx, keys, keys_alt, vals, vals_alt, n, key_shift, bits * spk_sort + key_shift));
 
-    // 4. first rerank (slots are SA positions)
+    // 4. first rerank (slots are SA positions).  Default: no rank array yet -- the suffixes that survive the initial sort are first
+    //    extended from the text (5a), which needs no ranks, and the rank array is built once, late, for whatever survives that (5b):
+    //    one bucketed scatter for the whole sort instead of one here plus tens of millions of random rank stores in the next round.
+    //    DK_RANKS_FIRST=1 (A/B and test hook): the rank array is built right here and the first round is a doubling round (not on the
+    //    probe's short-prefix path, which never has ranks this early).
     size_t active = 0, groups = 0, nbig = 0;
-    bool have_ranks = true;
     static const bool bucketed = [] { const char *e = getenv("DK_BUCKETED"); return !(e && e[0] == '0'); }();
+    static const bool ranks_first_env = [] { const char *e = getenv("DK_RANKS_FIRST"); return e && e[0] == '1'; }();
+    const bool ranks_first = ranks_first_env && !short_prefix;
+    bool have_ranks = ranks_first;
     const BwtCarry first_bc{key_shift, carry_bwt ? d_bwt : nullptr, d_inv, d_origin, nullptr, sym};
-    if (short_prefix) {
-        // few suffixes are expected to survive and they are finished from the text: no rank array unless that fails (step 5b)
-        DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, nullptr, d_sa, vals_alt, pos, gid, gstart, nullptr, false, nullptr, first_bc));
-        have_ranks = false;
+    if (!ranks_first) {
+        DK_TRY(rerank(ctx, keys, vals, nullptr, n, nullptr, nullptr, d_sa, vals_alt, pos, gid, gstart, nullptr, false, nullptr, first_bc));
     } else if (bucketed && n >= (1u << 22)) {
         // rank[suffix] = head position for all n suffixes: too random for plain stores (every 4-byte store is a 64-byte line
         // at the HBM) -> the rerank only lists the head positions, the bucketed scatter stores them XCD-locally
         bool need_ranks = true;
-        DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, rank, d_sa, vals_alt, pos, gid, gstart, vals_3, true, &need_ranks, first_bc));
+        DK_TRY(rerank(ctx, keys, vals, nullptr, n, nullptr, rank, d_sa, vals_alt, pos, gid, gstart, vals_3, true, &need_ranks, first_bc));
         if (need_ranks) DK_TRY(scatter_u32_bucketed(ctx, vals, vals_3, n, n, keys_alt, rank));
     } else {
-        DK_TRY(rerank(ctx, keys, vals, nullptr, n, -1, rank, d_sa, vals_alt, pos, gid, gstart, nullptr, true, nullptr, first_bc));
+        DK_TRY(rerank(ctx, keys, vals, nullptr, n, nullptr, rank, d_sa, vals_alt, pos, gid, gstart, nullptr, true, nullptr, first_bc));
     }
     DK_TRY(classify_and_read(ctx, n / 2, gstart, bigstart, &active, &groups, &nbig));
     std::swap(vals, vals_alt);  // vals = suffix indices of the active list
@@ -950,43 +969,54 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
                 carry_bwt ? " +prev" : "", active, groups, nbig);
 
     // one general round: secondary keys (ranks h further on, or the next tsym symbols of the text) -> every group sorted inside its
-    // own slot range (small groups in LDS, big ones through the global sort) -> rerank
-    auto run_round = [&](int kbits, int tsym) -> int {
-        const int gbits = static_cast<int>(ceil_log2_u64(groups));
+    // own slot range (small groups in LDS, big ones through the global sort) -> rerank.  Returns the symbols the round added (text
+    // rounds: the big groups' keys may hold fewer symbols than the small groups' -- the depth every group is known to is the smaller).
+    auto run_round = [&](int tsym, int *advanced) -> int {
         const uint32_t h_eff = static_cast<uint32_t>(std::min<uint64_t>(h, n));
+        const int bsbits = nbig > 1 ? static_cast<int>(ceil_log2_u64(nbig)) : 1;
+        int kbits, kb;
+        if (tsym > 0) {
+            kbits = tsym * bits;
+            const int tsym_big = std::min(tsym, (63 - bsbits) / bits);
+            kb = tsym_big * bits;
+            if (advanced) *advanced = nbig > 0 ? tsym_big : tsym;
+        } else {
+            kbits = kb = static_cast<int>(ceil_log2_u64(static_cast<uint64_t>(n) + h_eff));
+        }
         const TextSource ts{d_text, d_code, bits, tsym};
+        uint32_t *bslot = pos_alt;  // written by the rerank at the end of the round only: free until k_big_back has read it
         {
             LaunchScope ls(ctx, K_ROUND_LOCAL, 8.0 * active + 4.0 * active + 12.0 * active);
             if (tsym > 0)
                 k_round_local<true><<<dim3(div_up(active, LS_TILE)), dim3(LS_BLOCK), 0, st>>>(
-                    vals, gid, gstart, bigstart, rank, static_cast<uint32_t>(n), h_eff, kbits, active, keys, vals_alt, keys_alt, vals_3, ts, sym, sym_alt);
+                    vals, gid, gstart, bigstart, rank, static_cast<uint32_t>(n), h_eff, kbits, kb, active, keys, vals_alt, keys_alt, vals_3, bslot, ts, sym, sym_alt);
             else
                 k_round_local<false><<<dim3(div_up(active, LS_TILE)), dim3(LS_BLOCK), 0, st>>>(
-                    vals, gid, gstart, bigstart, rank, static_cast<uint32_t>(n), h_eff, kbits, active, keys, vals_alt, keys_alt, vals_3, ts, sym, sym_alt);
+                    vals, gid, gstart, bigstart, rank, static_cast<uint32_t>(n), h_eff, kbits, kb, active, keys, vals_alt, keys_alt, vals_3, bslot, ts, sym, sym_alt);
         }
         DK_HIP(ctx, hipGetLastError());
         if (nbig > 0) {
             uint64_t *bk = keys_alt, *bk_alt = keys_3;
             uint32_t *bv = vals_3, *bv_alt = vals_4;
-            DK_TRY(sort_pairs(ctx, bk, bk_alt, bv, bv_alt, nbig, 0, kbits + gbits));
+            DK_TRY(sort_pairs(ctx, bk, bk_alt, bv, bv_alt, nbig, 0, kb + bsbits));
             {
-                LaunchScope ls(ctx, K_BIG_BACK, 24.0 * nbig);
-                k_big_back<<<dim3(div_up(nbig, 256)), dim3(256), 0, st>>>(bk, bv, nbig, kbits, gstart, bigstart, keys, vals_alt, d_text,
-                                                                          static_cast<uint32_t>(n), carry_bwt ? sym_alt : nullptr);
+                LaunchScope ls(ctx, K_BIG_BACK, 28.0 * nbig);
+                k_big_back<<<dim3(div_up(nbig, 256)), dim3(256), 0, st>>>(bk, bv, bslot, nbig, keys, vals_alt, d_text, static_cast<uint32_t>(n),
+                                                                          carry_bwt ? sym_alt : nullptr);
             }
             DK_HIP(ctx, hipGetLastError());
         }
         // keys / vals_alt (/ sym_alt) now hold every group sorted by its secondary key in its own slot range
         size_t next_active = 0, next_groups = 0, next_big = 0;
         const BwtCarry bc{0, carry_bwt ? d_bwt : nullptr, nullptr, d_origin, sym_alt, sym};
-        DK_TRY(rerank(ctx, keys, vals_alt, pos, active, kbits, have_ranks ? rank : nullptr, d_sa, vals, pos_alt, gid_alt, gstart, nullptr, false,
+        DK_TRY(rerank(ctx, keys, vals_alt, pos, active, gid, have_ranks ? rank : nullptr, d_sa, vals, pos_alt, gid_alt, gstart, nullptr, false,
                       nullptr, bc));
         DK_TRY(classify_and_read(ctx, active / 2, gstart, bigstart, &next_active, &next_groups, &next_big, nbig == 0));
         std::swap(pos, pos_alt);
         std::swap(gid, gid_alt);
         if (trace)
-            fprintf(stderr, "[dk] round %u h=%llu%s slots=%zu big=%zu bits=%d -> active=%zu groups=%zu big=%zu\n", ctx->stats.rounds,
-                    (unsigned long long)h, tsym > 0 ? " (text)" : "", active, nbig, kbits + gbits, next_active, next_groups, next_big);
+            fprintf(stderr, "[dk] round %u h=%llu%s slots=%zu big=%zu key bits=%d (big %d+%d) -> active=%zu groups=%zu big=%zu\n", ctx->stats.rounds,
+                    (unsigned long long)h, tsym > 0 ? " (text)" : "", active, nbig, kbits, bsbits, kb, next_active, next_groups, next_big);
         active = next_active;
         groups = next_groups;
         nbig = next_big;
@@ -994,13 +1024,13 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
         return DK_OK;
     };
 
-    // 5a. short-prefix path: extend the survivors' keys from the text (as many further symbols as fit beside the group id)
-    for (int t = 0; short_prefix && active > 0 && t < 2; ++t) {
-        const int gbits = static_cast<int>(ceil_log2_u64(groups));
-        const int tsym = std::min(spk, (63 - gbits) / bits);
-        if (tsym < 1) break;
-        DK_TRY(run_round(tsym * bits, tsym));
-        h += static_cast<uint64_t>(tsym);
+    // 5a. extend the survivors' keys from the text: up to floor(63 / bits) further symbols per round, no ranks needed.  A second
+    //     such round only when the first left a lot (otherwise what is left are long repeats, which want doubling).
+    for (int t = 0; !have_ranks && active > 0 && t < 2; ++t) {
+        if (t == 1 && !short_prefix && active * 16 < n) break;
+        int adv = 0;
+        DK_TRY(run_round(std::min(spk, 63 / bits), &adv));
+        h += static_cast<uint64_t>(adv);
     }
     // 5b. survivors beyond that (long repeats): build the rank array the doubling rounds need
     if (active > 0 && !have_ranks) {
@@ -1021,15 +1051,14 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     static const bool plateau_enabled = [] { const char *e = getenv("DK_PLATEAU"); return !(e && e[0] == '0'); }();
     while (active > 0 && (nbig > 0 || !plateau_enabled)) {
         if (ctx->stats.rounds > 44) return ctx->fail(DK_E_INTERNAL, "suffix_array: no convergence after 44 rounds");
-        const uint32_t h_eff = static_cast<uint32_t>(std::min<uint64_t>(h, n));
-        DK_TRY(run_round(static_cast<int>(ceil_log2_u64(static_cast<uint64_t>(n) + h_eff)), 0));
+        DK_TRY(run_round(0, nullptr));
         h *= 2;
     }
     // ... then in place (k_plateau_sort): one sort kernel + one rank kernel per round, the live count read back one round late
     if (active > 0) {
         size_t slots = active;
         uint32_t *idx_a = vals, *idx_b = vals_alt;
-        uint16_t *meta_a = reinterpret_cast<uint16_t *>(gid), *meta_b = reinterpret_cast<uint16_t *>(gid_alt);
+        uint32_t *meta_a = gid, *meta_b = gid_alt;
         uint8_t *sym_a = sym, *sym_b = sym_alt;
         uint32_t *d_live = ctx->d_mail + 700, *h_live = ctx->h_mail + 700;  // ring of 8 counters
         {
