@@ -543,7 +543,50 @@ __device__ __forceinline__ uint32_t rank2_of(const uint32_t *__restrict__ rank, 
 
 // TEXT = true (text-extension round of the short-prefix path): the secondary key is not a rank but the next `tsym` symbols of the
 // text after the h already sorted ones, packed like the initial keys (64-bit secondary keys in LDS).
+// bits == 0: RAW mode -- the key is the next eight BYTES of the text, big-endian (the byte order is the symbol order, so no code table
+// is needed; one or two aligned 8-byte loads per suffix).  Otherwise tsym symbols through the code table (small alphabets: more
+// symbols per 64 bits), the table staged in LDS.
 struct TextSource { const uint8_t *text; const uint8_t *code; int bits; int tsym; };
+
+// bytes T[p .. p+8) as a big-endian integer, zero padded past the end of the text
+__device__ __forceinline__ uint64_t text_key_raw(const uint8_t *__restrict__ t, size_t n, size_t p) {
+    if (p + 16 <= n) {  // both aligned words lie inside the text
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(t) + p;
+        const uint64_t *q = reinterpret_cast<const uint64_t *>(addr & ~static_cast<uintptr_t>(7));
+        const unsigned sh = static_cast<unsigned>(addr & 7u) * 8u;
+        const uint64_t lo = q[0];
+        uint64_t v = lo;
+        if (sh) v = (lo >> sh) | (q[1] << (64u - sh));
+        return __builtin_bswap64(v);
+    }
+    uint64_t key = 0;
+    for (int j = 0; j < 8; ++j) key = (key << 8) | (p + j < n ? t[p + j] : 0u);
+    return key;
+}
+// tsym symbols from p on through the (LDS) code table, packed big-endian, zero padded past the end
+__device__ __forceinline__ uint64_t text_key_coded(const uint8_t *__restrict__ t, size_t n, const uint8_t *s_code, size_t p, int bits, int count) {
+    uint64_t key = 0;
+    int j = 0;
+    if (p + static_cast<size_t>(count) + 8 <= n) {
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(t) + p;
+        const uint64_t *q = reinterpret_cast<const uint64_t *>(addr & ~static_cast<uintptr_t>(7));
+        int skip = static_cast<int>(addr & 7u);
+        while (j < count) {
+            uint64_t w = *q++ >> (8 * skip);
+            for (int b = skip; b < 8 && j < count; ++b, ++j) {
+                key = (key << bits) | s_code[w & 0xFFu];
+                w >>= 8;
+            }
+            skip = 0;
+        }
+        return key;
+    }
+    for (; j < count; ++j) {
+        const size_t q = p + j;
+        key = (key << bits) | (q < n ? s_code[t[q]] : 0u);
+    }
+    return key;
+}
 
 // Small groups: key_out = the secondary key alone (the rerank compares keys inside an old group only).  Big groups: the global sort
 // must keep every group in its range of the big list, so its key is (offset of the group in the big list) above the secondary key,
@@ -559,11 +602,19 @@ __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__rest
                                                           const uint8_t *__restrict__ sym_in, uint8_t *__restrict__ sym_out) {
     using R2 = typename std::conditional<TEXT, uint64_t, uint32_t>::type;
     __shared__ R2 s_r2[LS_TILE + 2 * LS_MAX];
+    __shared__ uint8_t s_code[TEXT ? 256 : 4];
+    const int tid = threadIdx.x;
+    if (TEXT && ts.bits) {
+        s_code[tid] = ts.code[tid];
+        __syncthreads();
+    }
     auto second = [&](uint32_t suffix) -> R2 {
-        if (TEXT) return static_cast<R2>(text_key(ts.text, n, ts.code, static_cast<size_t>(suffix) + h, ts.bits, ts.tsym));
+        if (TEXT) {
+            const size_t p = static_cast<size_t>(suffix) + h;
+            return static_cast<R2>(ts.bits ? text_key_coded(ts.text, n, s_code, p, ts.bits, ts.tsym) : text_key_raw(ts.text, n, p));
+        }
         return static_cast<R2>(rank2_of(rank, suffix, n, h));
     };
-    const int tid = threadIdx.x;
     const size_t b0 = static_cast<size_t>(blockIdx.x) * LS_TILE;
     uint32_t my_idx[LS_IPT];
     R2 my_r2[LS_IPT];
@@ -975,15 +1026,18 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
         const uint32_t h_eff = static_cast<uint32_t>(std::min<uint64_t>(h, n));
         const int bsbits = nbig > 1 ? static_cast<int>(ceil_log2_u64(nbig)) : 1;
         int kbits, kb;
+        const bool raw_text = tsym > 0 && bits >= 5;  // eight raw bytes per key beat the code table unless the alphabet is small
+        const int tbits = raw_text ? 8 : bits;
         if (tsym > 0) {
-            kbits = tsym * bits;
-            const int tsym_big = std::min(tsym, (63 - bsbits) / bits);
-            kb = tsym_big * bits;
+            if (raw_text) tsym = 8;
+            kbits = tsym * tbits;
+            const int tsym_big = std::min(tsym, (63 - bsbits) / tbits);
+            kb = tsym_big * tbits;
             if (advanced) *advanced = nbig > 0 ? tsym_big : tsym;
         } else {
             kbits = kb = static_cast<int>(ceil_log2_u64(static_cast<uint64_t>(n) + h_eff));
         }
-        const TextSource ts{d_text, d_code, bits, tsym};
+        const TextSource ts{d_text, d_code, raw_text ? 0 : bits, tsym};
         uint32_t *bslot = pos_alt;  // written by the rerank at the end of the round only: free until k_big_back has read it
         {
             LaunchScope ls(ctx, K_ROUND_LOCAL, 8.0 * active + 4.0 * active + 12.0 * active);
@@ -1027,7 +1081,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     // 5a. extend the survivors' keys from the text: up to floor(63 / bits) further symbols per round, no ranks needed.  A second
     //     such round only when the first left a lot (otherwise what is left are long repeats, which want doubling).
     for (int t = 0; !have_ranks && active > 0 && t < 2; ++t) {
-        if (t == 1 && !short_prefix && active * 16 < n) break;
+        if (t == 1 && !short_prefix && active * 8 < n) break;
         int adv = 0;
         DK_TRY(run_round(std::min(spk, 63 / bits), &adv));
         h += static_cast<uint64_t>(adv);
