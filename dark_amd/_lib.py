@@ -41,6 +41,8 @@ SIGNATURES = {
     "dk_dc_decode": (_i, [_vp, _vp, _vp, _sz, _vp, _sz, _szp]),
     "dk_block_encode": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _szp]),
     "dk_block_decode": (_i, [_vp, _i, _vp, _sz, _sz, _vp]),
+    "dk_raw_block_encode": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _szp, _vp, _sz, _szp]),
+    "dk_raw_block_decode": (_i, [_vp, _i, _vp, _sz, _sz, _vp]),
     "dk_dev_suffix_array": (_i, [_vp, _vp, _sz, _vp]),
     "dk_dev_bwt_forward": (_i, [_vp, _vp, _sz, _vp, _u32p]),
     "dk_dev_bwt_inverse": (_i, [_vp, _vp, _sz, C.c_uint32, _vp]),

@@ -1,87 +1,385 @@
 """Command line front end with the reference's conventions (src/main.rs:34-116).
 
-    python -m dark_amd.cli [-m dark|exp|ybs|simple|rawdc] FILE          -> ./FILE.dark   = [u32 LE n][coded stream]
-    python -m dark_amd.cli [-m MODEL] FILE.dark                         -> ./FILE.orig
+    python -m dark_amd.cli [-m dark|exp|ybs|simple|raw|rawdc] FILE        -> ./FILE with its extension replaced by .dark
+    python -m dark_amd.cli [-m MODEL] FILE.dark                           -> ./FILE.orig
 
-The default model is `exp`, as in src/main.rs:52.  A file made here with one block is byte-for-byte what the reference writes
-(to the extent DESIGN.md section 2 pins it).  Extension beyond the reference: `-b BYTES` cuts the input into blocks and
-concatenates their records; decoding walks the records (each decode reports how many stream bytes it consumed).  The reference
-reads such a file as its first block only.
+The default model is `exp`, as in src/main.rs:52.  Output names follow PathBuf::set_extension (src/main.rs:64-66,96-98):
+book.txt -> book.dark, book -> book.dark, book.dark -> book.orig; the output lands in the current directory.  A file made here with
+one block is byte-for-byte what the reference writes: [u32 LE n][coded stream] (to the extent DESIGN.md section 2 pins it).
+
+Extensions beyond the reference (whole file = one block, read into memory, one thread):
+  -b BYTES   cut the input into blocks; records [u32 LE n][stream] are concatenated, each byte-identical to a single-block run on that
+             block, followed by an index footer (record offsets) so that decoding can be batched and spread over GPUs.  The reference
+             reads such a file as its first block only.  Blocks are STREAMED: one block of input is in host memory at a time, batches of
+             blocks live in HBM and go through dk_dev_batch_encode (GPU stages of block i+1 overlap the host coding of earlier blocks).
+  --gpus G   block b -> GPU b mod G, one worker process per GPU; the parent never touches a GPU and stitches the records in order.
+  --force    encode blocks that contain byte 0xFF.  The reference's header cannot carry that symbol (src/block/dc.rs:57,60,73,127):
+             it writes such an archive without complaint and can never decode it.  This front end refuses unless --force is given.
 """
 import argparse
 import os
 import struct
+import subprocess
 import sys
+import threading
+import queue
 
 import numpy as np
 
-EXTENSION = ".dark"
+EXTENSION = "dark"
+FOOTER_MAGIC = b"DKIX"
+DUMP_MODELS = ("raw", "rawdc")
 
 
-def encode_file(path, model, block_size, device):
+def set_extension(name, ext):
+    """std::path::PathBuf::set_extension on a bare file name: the part after the last '.' is replaced (a leading '.' alone does not start
+    an extension); a name without extension gets one appended."""
+    i = name.rfind(".")
+    stem = name[:i] if i > 0 else name
+    return stem + "." + ext
+
+
+def output_name(path, ext):
+    return set_extension(os.path.basename(path), ext)  # main.rs:96-98 / 64-66: file name only -> current directory
+
+
+def has_extension(path, ext):
+    name = os.path.basename(path)
+    i = name.rfind(".")
+    return i > 0 and name[i + 1:] == ext
+
+
+class Refused(SystemExit):
+    pass
+
+
+def _check_ff(block, force, where):
+    if not force and bool((block == 255).any()):
+        raise Refused("%s contains byte 0xFF: the reference format cannot carry that symbol (src/block/dc.rs:57-73), the archive could "
+                      "never be decoded.  Pass --force to write it anyway (bit-exact with what the reference writes)." % where)
+
+
+# ---- single block: the reference's own behaviour ------------------------------------------------------------------------------------
+def _encode_single(path, model, device, force, out_path):
     from .context import Context
-    data = np.fromfile(path, dtype=np.uint8)
-    n_total = len(data)
-    if n_total == 0:
+    data = np.fromfile(path, dtype=np.uint8)  # main.rs:87-95 reads the whole file: one block
+    n = len(data)
+    if n == 0:
         raise SystemExit("empty input: the reference panics on it (src/saca.rs:107)")
-    bs = block_size or n_total
-    out_path = os.path.basename(path) + EXTENSION  # like main.rs:96-98: next to the CWD, input name + .dark
-    with Context(min(bs, n_total), device) as ctx, open(out_path, "wb") as out:
-        for off in range(0, n_total, bs):
-            block = data[off:off + bs]
-            out.write(struct.pack("<I", len(block)))          # main.rs:102
-            if model == "raw":
-                # block::raw::Encoder with model::raw::Out (src/block/raw.rs:35-59, src/model/raw.rs:46-76): origin as four
-                # symbols then every BWT byte go to ./out.raw; nothing reaches the coder, whose tail is four zero bytes
-                bwt, origin = ctx.bwt_forward(block)
-                with open("out.raw", "ab" if off else "wb") as dump:
-                    dump.write(struct.pack(">I", origin))
-                    dump.write(bwt.tobytes())
-                out.write(b"\0\0\0\0")
-            elif model == "rawdc":
-                # block::dc::Encoder with model::raw::DcOut (src/model/raw.rs:12-44): 10-byte records go to ./out-dc.raw
-                with open("out-dc.raw", "ab" if off else "wb") as dump:
-                    dump.write(ctx.block_encode("rawdc", block))
-                out.write(b"\0\0\0\0")
-            else:
-                out.write(ctx.block_encode(model, block))     # main.rs:104-113
+    with Context(n, device) as ctx, open(out_path, "wb") as out:
+        out.write(struct.pack("<I", n))                   # main.rs:102
+        _write_block(ctx, model, data, out, True, force)
     return out_path
 
 
-def decode_file(path, model, device):
+def _write_block(ctx, model, block, out, first, force):
+    if model == "raw":
+        # block::raw::Encoder with model::raw::Out (src/block/raw.rs:35-59, src/model/raw.rs:46-76): origin as four symbols, then every
+        # BWT byte, go to ./out.raw; nothing reaches the coder, whose tail is four zero bytes
+        with open("out.raw", "wb" if first else "ab") as dump:
+            dump.write(ctx.raw_block_encode_dump(block))
+        out.write(b"\0\0\0\0")
+    elif model == "rawdc":
+        # block::dc::Encoder with model::raw::DcOut (src/model/raw.rs:12-44): 10-byte records go to ./out-dc.raw
+        with open("out-dc.raw", "wb" if first else "ab") as dump:
+            dump.write(ctx.block_encode("rawdc", block))
+        out.write(b"\0\0\0\0")
+    else:
+        _check_ff(block, force, "the block")
+        out.write(ctx.block_encode(model, block))         # main.rs:104-113
+
+
+# ---- streamed, batched encode on one GPU ---------------------------------------------------------------------------------------------
+def _reader(f, block_size, first_block, step, total_blocks, batch, q, force, device):
+    """reads block indices first_block, first_block+step, ... one at a time, uploads each to HBM, hands over batches of device tensors"""
+    import torch
+    try:
+        cur = []
+        for b in range(first_block, total_blocks, step):
+            f.seek(b * block_size)
+            block = np.fromfile(f, dtype=np.uint8, count=block_size)  # ONE block of input in host memory
+            _check_ff(block, force, "block %d" % b)
+            cur.append((b, len(block), torch.from_numpy(block).to("cuda:%d" % device)))
+            del block
+            if len(cur) == batch:
+                q.put(cur)
+                cur = []
+        if cur:
+            q.put(cur)
+        q.put(None)
+    except BaseException as e:  # noqa: BLE001 -- handed to the consumer, which re-raises
+        q.put(e)
+
+
+def _encode_blocks(path, model, block_size, device, first_block, step, total_blocks, out, index, force, host_threads):
+    """encode blocks first_block, first_block+step, ... of `path` in order into `out`; index gets (block number, record length)"""
+    import torch
     from .context import Context
-    blob = np.fromfile(path, dtype=np.uint8)
-    base = os.path.basename(path)
-    out_path = base[:-len(EXTENSION)] + ".orig"             # main.rs:64-66
-    pos, ctx = 0, None
+    torch.cuda.set_device(device)
+    batch = max(2, host_threads)
+    q = queue.Queue(maxsize=1)  # one batch being read ahead while one is being encoded
+    with open(path, "rb") as f, Context(block_size, device) as ctx:
+        t = threading.Thread(target=_reader, args=(f, block_size, first_block, step, total_blocks, batch, q, force, device), daemon=True)
+        t.start()
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            sizes = [n for _, n, _ in item]
+            streams = ctx.dev_batch_encode(model, [d for _, _, d in item], sizes, host_threads)
+            for (b, n, _), s in zip(item, streams):
+                out.write(struct.pack("<I", n))
+                out.write(memoryview(s))
+                index.append((b, 4 + len(s)))
+            del item, streams
+        t.join()
+
+
+def _write_footer(out, offsets):
+    """index of a multi-record file: 'DKIX' u32 count, count x u64 record offsets, u64 offset of this footer, 'DKIX'"""
+    start = out.tell()
+    out.write(FOOTER_MAGIC + struct.pack("<I", len(offsets)))
+    out.write(struct.pack("<%dQ" % len(offsets), *offsets))
+    out.write(struct.pack("<Q", start) + FOOTER_MAGIC)
+
+
+def read_footer(path):
+    """-> list of record offsets + the offset where the records end, or None for a file without index (single block / legacy)"""
+    size = os.path.getsize(path)
+    if size < 24:
+        return None
+    with open(path, "rb") as f:
+        f.seek(size - 12)
+        tail = f.read(12)
+        if tail[8:] != FOOTER_MAGIC:
+            return None
+        (start,) = struct.unpack("<Q", tail[:8])
+        if start + 20 > size:
+            return None
+        f.seek(start)
+        head = f.read(8)
+        if head[:4] != FOOTER_MAGIC:
+            return None
+        (count,) = struct.unpack("<I", head[4:])
+        if start + 8 + 8 * count + 12 != size:
+            return None
+        offs = list(struct.unpack("<%dQ" % count, f.read(8 * count)))
+    return offs, start
+
+
+def _host_threads():
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        cpus = max(1, int(q) // int(period)) if q != "max" else (os.cpu_count() or 1)
+    except (OSError, ValueError):
+        cpus = os.cpu_count() or 1
+    return cpus
+
+
+def _devices(device, gpus, devices):
+    """GPU of worker r: --devices a,b,... (e.g. 0,0 rehearses two workers on a one-GPU box), else device + r"""
+    if devices:
+        ids = [int(x) for x in str(devices).split(",")]
+        if len(ids) != gpus:
+            raise SystemExit("--devices needs exactly --gpus entries")
+        return ids
+    return [device + r for r in range(gpus)]
+
+
+def encode_file(path, model, block_size=0, device=0, gpus=1, force=False, host_threads=0, devices=None):
+    out_path = output_name(path, EXTENSION)
+    total = os.path.getsize(path)
+    if total == 0:
+        raise SystemExit("empty input: the reference panics on it (src/saca.rs:107)")
+    if not block_size or block_size >= total:
+        return _encode_single(path, model, device, force, out_path)
+    nblocks = -(-total // block_size)
+    if model in DUMP_MODELS:  # dump-only models: block after block through the host entry points
+        from .context import Context
+        with open(path, "rb") as f, Context(block_size, device) as ctx, open(out_path, "wb") as out:
+            for b in range(nblocks):
+                block = np.fromfile(f, dtype=np.uint8, count=block_size)
+                out.write(struct.pack("<I", len(block)))
+                _write_block(ctx, model, block, out, b == 0, force)
+        return out_path
+    threads = host_threads or max(1, _host_threads() // max(1, gpus) - 1)
+    if gpus <= 1:
+        index = []
+        with open(out_path, "wb") as out:
+            _encode_blocks(path, model, block_size, device, 0, 1, nblocks, out, index, force, threads)
+            offsets, pos = [], 0
+            for _, ln in index:
+                offsets.append(pos)
+                pos += ln
+            _write_footer(out, offsets)
+        return out_path
+    # one worker process per GPU (block b -> GPU b mod G); this parent has not touched and does not touch a GPU
+    parts = ["%s.part%d" % (out_path, r) for r in range(gpus)]
+    procs = []
+    devs = _devices(device, gpus, devices)
+    for r in range(gpus):
+        cmd = [sys.executable, "-m", "dark_amd.cli", "--worker", "%d/%d" % (r, gpus), "--part", parts[r], "-m", model, "-b", str(block_size),
+               "-d", str(devs[r]), "--host-threads", str(threads)] + (["--force"] if force else []) + [path]
+        procs.append(subprocess.Popen(cmd, env=dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] +
+                                                                                               os.environ.get("PYTHONPATH", "").split(os.pathsep)))))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:
+        for part in parts:
+            for name in (part, part + ".idx"):
+                if os.path.exists(name):
+                    os.remove(name)
+        raise SystemExit("a GPU worker failed (exit code %d)" % rc)
+    # stitch: records in block order, each worker's part holds its blocks in its own order
+    lens = [[int(x) for x in open(part + ".idx").read().split()] for part in parts]
+    files = [open(part, "rb") for part in parts]
+    offsets, pos = [], 0
     with open(out_path, "wb") as out:
-        while pos < len(blob):
-            if pos + 4 > len(blob):
-                raise SystemExit("truncated record header at byte %d" % pos)
-            (n,) = struct.unpack("<I", blob[pos:pos + 4].tobytes())   # main.rs:70
-            pos += 4
-            if ctx is None or ctx.capacity() < n:
-                if ctx is not None:
-                    ctx.close()
-                ctx = Context(n, device)
-            out.write(ctx.block_decode(model, blob[pos:], n))
-            pos += ctx.last_consumed()
-    if ctx is not None:
-        ctx.close()
+        for b in range(nblocks):
+            r, k = b % gpus, b // gpus
+            ln = lens[r][k]
+            offsets.append(pos)
+            out.write(files[r].read(ln))
+            pos += ln
+        _write_footer(out, offsets)
+    for fobj, part in zip(files, parts):
+        fobj.close()
+        os.remove(part)
+        os.remove(part + ".idx")
     return out_path
+
+
+def _worker_encode(args):
+    r, g = (int(x) for x in args.worker.split("/"))
+    total = os.path.getsize(args.file)
+    nblocks = -(-total // args.block_size)
+    index = []
+    with open(args.part, "wb") as out:
+        _encode_blocks(args.file, args.model, args.block_size, args.device, r, g, nblocks, out, index, args.force, args.host_threads or 1)
+    with open(args.part + ".idx", "w") as f:
+        f.write(" ".join(str(ln) for _, ln in index))
+
+
+# ---- decode -----------------------------------------------------------------------------------------------------------------------------
+def _decode_records_batched(path, model, device, offsets, end, which, out_write, host_threads):
+    """decode records `which` (indices into offsets) through dk_dev_batch_decode, in batches; out_write(k, bytes) receives them in order"""
+    import torch
+    from .context import Context
+    torch.cuda.set_device(device)
+    batch = max(2, host_threads)
+    bounds = offsets + [end]
+    with open(path, "rb") as f:
+        sizes = []
+        for k in which:
+            f.seek(offsets[k])
+            sizes.append(struct.unpack("<I", f.read(4))[0])
+        if not sizes:
+            return
+        with Context(max(sizes), device) as ctx:
+            for lo in range(0, len(which), batch):
+                ks = which[lo:lo + batch]
+                ns = sizes[lo:lo + batch]
+                streams = []
+                for k in ks:
+                    f.seek(offsets[k] + 4)
+                    streams.append(np.fromfile(f, dtype=np.uint8, count=bounds[k + 1] - offsets[k] - 4))
+                d_outs = [torch.empty(n, dtype=torch.uint8, device="cuda:%d" % device) for n in ns]
+                ctx.dev_batch_decode(model, streams, ns, d_outs, host_threads)
+                for k, d in zip(ks, d_outs):
+                    out_write(k, d.cpu().numpy().tobytes())
+                del d_outs, streams
+
+
+def decode_file(path, model, device=0, gpus=1, host_threads=0, devices=None):
+    from .context import Context
+    out_path = output_name(path, "orig")                    # main.rs:64-66
+    if model in DUMP_MODELS:
+        raise SystemExit("model %s is dump-only: there is nothing to decode (src/model/raw.rs:39-43 panics)" % model)
+    footer = read_footer(path)
+    threads = host_threads or max(1, _host_threads() // max(1, gpus) - 1)
+    if footer is None:
+        # no index: the reference's single-block file (main.rs:70), or concatenated records walked by the bytes each decode consumed
+        size = os.path.getsize(path)
+        with open(path, "rb") as f, open(out_path, "wb") as out:
+            blob = np.fromfile(f, dtype=np.uint8)
+            pos, ctx = 0, None
+            while pos < size:
+                if pos + 4 > size:
+                    raise SystemExit("truncated record header at byte %d" % pos)
+                (n,) = struct.unpack("<I", blob[pos:pos + 4].tobytes())   # main.rs:70
+                pos += 4
+                if ctx is None or ctx.capacity() < n:
+                    if ctx is not None:
+                        ctx.close()
+                    ctx = Context(n, device)
+                out.write(ctx.block_decode(model, blob[pos:], n))
+                pos += ctx.last_consumed()
+            if ctx is not None:
+                ctx.close()
+        return out_path
+    offsets, end = footer
+    if gpus <= 1:
+        with open(out_path, "wb") as out:
+            _decode_records_batched(path, model, device, offsets, end, list(range(len(offsets))), lambda k, data: out.write(data), threads)
+        return out_path
+    parts = ["%s.part%d" % (out_path, r) for r in range(gpus)]
+    procs = []
+    devs = _devices(device, gpus, devices)
+    for r in range(gpus):
+        cmd = [sys.executable, "-m", "dark_amd.cli", "--worker", "%d/%d" % (r, gpus), "--part", parts[r], "-m", model, "-d", str(devs[r]),
+               "--host-threads", str(threads), path]
+        procs.append(subprocess.Popen(cmd, env=dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] +
+                                                                                               os.environ.get("PYTHONPATH", "").split(os.pathsep)))))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:
+        raise SystemExit("a GPU worker failed (exit code %d)" % rc)
+    files = [open(part, "rb") for part in parts]
+    with open(path, "rb") as f, open(out_path, "wb") as out:
+        for k in range(len(offsets)):
+            f.seek(offsets[k])
+            (n,) = struct.unpack("<I", f.read(4))
+            out.write(files[k % gpus].read(n))
+    for fobj, part in zip(files, parts):
+        fobj.close()
+        os.remove(part)
+    return out_path
+
+
+def _worker_decode(args):
+    r, g = (int(x) for x in args.worker.split("/"))
+    offsets, end = read_footer(args.file)
+    with open(args.part, "wb") as out:
+        _decode_records_batched(args.file, args.model, args.device, offsets, end, list(range(r, len(offsets), g)), lambda k, data: out.write(data),
+                                args.host_threads or 1)
 
 
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="dark_amd.cli", description="Dark compressor usage: [options] input_file[.dark]")
     ap.add_argument("-m", "--model", default="exp", help="dark|exp|ybs|simple|raw|rawdc (default exp, like the reference; raw and rawdc are dump-only)")
-    ap.add_argument("-b", "--block-size", type=int, default=0, help="cut the input into blocks of this many bytes (extension)")
+    ap.add_argument("-b", "--block-size", type=int, default=0, help="cut the input into blocks of this many bytes (extension; streamed and batched)")
     ap.add_argument("-d", "--device", type=int, default=0)
+    ap.add_argument("--gpus", type=int, default=1, help="block b -> GPU b mod G, one worker process per GPU (needs -b / an indexed archive)")
+    ap.add_argument("--force", action="store_true", help="write archives of blocks containing byte 0xFF (undecodable in the reference format)")
+    ap.add_argument("--host-threads", type=int, default=0, help="host coding threads per GPU (default: CPU quota / gpus - 1)")
+    ap.add_argument("--devices", default="", help="GPU ids of the workers, comma separated (default: device, device+1, ...)")
+    ap.add_argument("--worker", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--part", default="", help=argparse.SUPPRESS)
     ap.add_argument("file")
     args = ap.parse_args(argv)
-    if args.file.endswith(EXTENSION):
-        print(decode_file(args.file, args.model, args.device))
+    decode = has_extension(args.file, EXTENSION)           # main.rs:56: direction by extension
+    if args.worker:
+        return _worker_decode(args) if decode else _worker_encode(args)
+    if decode:
+        print(decode_file(args.file, args.model, args.device, args.gpus, args.host_threads, args.devices))
     else:
-        print(encode_file(args.file, args.model, args.block_size, args.device))
+        print(encode_file(args.file, args.model, args.block_size, args.device, args.gpus, args.force, args.host_threads, args.devices))
 
 
 if __name__ == "__main__":

@@ -143,6 +143,23 @@ class Context:
         self._ck(self._lib.dk_block_decode(self._h, model_id(model), _ptr(s), len(s), n, _ptr(out)))
         return out.tobytes()
 
+    def raw_block_encode_dump(self, data, raw_model=0):
+        """block::raw::Encoder with the dump model Out (src/block/raw.rs:35-59, src/model/raw.rs:46-76) -> what lands in ./out.raw"""
+        t = as_u8(data)
+        n = len(t)
+        out = np.empty(8, dtype=np.uint8)
+        dump = np.empty(n + 4, dtype=np.uint8)
+        ln, dl = C.c_size_t(0), C.c_size_t(0)
+        self._ck(self._lib.dk_raw_block_encode(self._h, int(raw_model), _ptr(t), n, _ptr(out), len(out), C.byref(ln), _ptr(dump), len(dump), C.byref(dl)))
+        assert ln.value == 4 and not out[:4].any()
+        return dump[:dl.value].tobytes()
+
+    def raw_block_decode(self, stream, n, raw_model=0):
+        s = as_u8(stream)
+        out = np.empty(n, dtype=np.uint8)
+        self._ck(self._lib.dk_raw_block_decode(self._h, int(raw_model), _ptr(s), len(s), n, _ptr(out)))
+        return out.tobytes()
+
     # ---- device-resident calls (torch tensors or raw device addresses) ----
     def dev_suffix_array(self, d_in, n, d_sa_out):
         _inputs_ready(d_in)

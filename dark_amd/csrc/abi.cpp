@@ -571,6 +571,48 @@ int dk_block_decode(dk_ctx *ctx, int model_id, const uint8_t *in, size_t in_len,
     return DK_OK;
 }
 
+// block::raw::Encoder::encode (src/block/raw.rs:35-59) with the dump model Out: SA -> BWT on the GPU, origin + L into `dump`
+int dk_raw_block_encode(dk_ctx *ctx, int raw_model, const uint8_t *in, size_t n, uint8_t *out, size_t out_cap, size_t *out_len, uint8_t *dump,
+                        size_t dump_cap, size_t *dump_len) {
+    DK_TRY(begin_call(ctx));
+    ScopedCall sc(ctx);
+    if (!in || !out || !out_len) return ctx->fail(DK_E_ARG, "null pointer");
+    if (raw_model == DK_RAWMODEL_BBB)
+        return ctx->fail(DK_E_MODEL, "the bbb model needs compress::entropy::ari::apm::Gate, which is not part of the reference tree");
+    if (raw_model != DK_RAWMODEL_OUT) return ctx->fail(DK_E_MODEL, "unknown raw model %d", raw_model);
+    if (!dump || !dump_len) return ctx->fail(DK_E_ARG, "the Out model needs a dump buffer");
+    DK_TRY(check_n(ctx, n));
+    if (dump_cap < n + 4 || out_cap < 4) return ctx->fail(DK_E_CAPACITY, "dump needs n + 4 bytes, out 4 bytes");
+    Timer t;
+    uint8_t *d_text = ctx->ws_alloc<uint8_t>(n);
+    uint8_t *d_bwt = ctx->ws_alloc<uint8_t>(n);
+    uint32_t *d_sa = ctx->ws_alloc<uint32_t>(n);
+    if (!d_text || !d_bwt || !d_sa) return DK_E_NOMEM;
+    DK_HIP(ctx, hipMemcpyAsync(d_text, in, n, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t origin = 0;
+    DK_TRY(bwt_forward_device(ctx, d_text, n, d_sa, d_bwt, &origin));
+    DK_HIP(ctx, hipMemcpyAsync(dump + 4, d_bwt, n, hipMemcpyDeviceToHost, ctx->stream));
+    DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 4; ++i) dump[i] = static_cast<uint8_t>(origin >> (24 - 8 * i));  // src/block/raw.rs:48-51
+    *dump_len = n + 4;
+    std::memset(out, 0, 4);  // ari::Encoder::finish of a coder nothing was coded with: low = 0, four bytes
+    *out_len = 4;
+    ctx->stats.ms_total = t.ms();
+    return DK_OK;
+}
+
+int dk_raw_block_decode(dk_ctx *ctx, int raw_model, const uint8_t *in, size_t in_len, size_t n, uint8_t *out) {
+    DK_TRY(begin_call(ctx));
+    if (!in || !out) return ctx->fail(DK_E_ARG, "null pointer");
+    (void)in_len;
+    if (raw_model == DK_RAWMODEL_BBB)
+        return ctx->fail(DK_E_MODEL, "the bbb model needs compress::entropy::ari::apm::Gate, which is not part of the reference tree");
+    if (raw_model != DK_RAWMODEL_OUT) return ctx->fail(DK_E_MODEL, "unknown raw model %d", raw_model);
+    DK_TRY(check_n(ctx, n));
+    std::memset(out, 0, n);  // Out::decode returns symbol 0 ("not supported", src/model/raw.rs:71-75): origin 0, a BWT of zeros -> n zeros
+    return DK_OK;
+}
+
 // ---- model / coder level (host only) --------------------------------------------------------------------------------------
 int dk_model_encode(int model_id, const uint32_t *dist, const uint8_t *sym, size_t m, uint8_t *out, size_t out_cap, size_t *out_len) {
     if ((!dist || !sym) && m) return DK_E_ARG;

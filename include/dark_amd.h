@@ -79,6 +79,18 @@ int dk_block_encode(dk_ctx *ctx, int model_id, const uint8_t *in, size_t n,
                     uint8_t *out, size_t out_cap, size_t *out_len);
 /* block::Decoder::decode for block::dc::Decoder<M> src/block/dc.rs:119-160 */
 int dk_block_decode(dk_ctx *ctx, int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *out);
+/* block::raw::{Encoder,Decoder}<M: RawModel> src/block/raw.rs:17-105: SA -> BWT, then origin as four symbols (bits 31..24 first,
+ * src/block/raw.rs:48-51) and every BWT byte through the RawModel.  RawModels of the reference:
+ *   DK_RAWMODEL_OUT  model::raw::Out src/model/raw.rs:46-76: every symbol is appended to ./out.raw, nothing reaches the coder.  Here the
+ *                    symbols come back in `dump` (n + 4 bytes) and `out` receives what the idle coder's finish() writes (4 zero bytes).
+ *                    Decoding "is not supported" in the reference (raw.rs:71-75 returns symbol 0 for everything): n zero bytes, DK_OK.
+ *   DK_RAWMODEL_BBB  model::bbb::Model src/model/bbb.rs: not built -- its gates are compress::entropy::ari::apm::Gate, whose arithmetic
+ *                    is in the un-vendored crate and appears nowhere in the reference tree; DK_E_MODEL. */
+#define DK_RAWMODEL_OUT 0
+#define DK_RAWMODEL_BBB 1
+int dk_raw_block_encode(dk_ctx *ctx, int raw_model, const uint8_t *in, size_t n, uint8_t *out, size_t out_cap, size_t *out_len,
+                        uint8_t *dump, size_t dump_cap, size_t *dump_len);
+int dk_raw_block_decode(dk_ctx *ctx, int raw_model, const uint8_t *in, size_t in_len, size_t n, uint8_t *out);
 /* Bytes of `in` the last dk_block_decode / dk_dev_block_decode on this context consumed (= the length the encoder wrote:
  * 4 priming bytes + one per renormalisation shift).  Lets a caller walk concatenated [u32 n][stream] records -- the
  * multi-block extension of the single-block file of src/main.rs:70,102. */

@@ -200,3 +200,13 @@ def test_reciprocal_division_is_exact():
         for span in spans:
             if 0 <= span < (1 << 32):
                 assert (span * inv) >> 64 == span // total, (span, total)
+
+
+def test_cli_names_follow_set_extension():
+    # std::path::PathBuf::set_extension as used at src/main.rs:64-66,96-98
+    from dark_amd import cli
+    for name, want in (("book1", "book1.dark"), ("book.txt", "book.dark"), ("a.tar.gz", "a.tar.dark"), (".hidden", ".hidden.dark"),
+                       ("dir/sub/x.bin", "x.dark"), ("trailing.", "trailing.dark")):
+        assert cli.output_name(name, "dark") == want, name
+    assert cli.output_name("book.dark", "orig") == "book.orig"
+    assert cli.has_extension("x/book.dark", "dark") and not cli.has_extension(".dark", "dark") and not cli.has_extension("dark", "dark")

@@ -187,15 +187,35 @@ def test_cli_container(tmp_path, orc, license_bytes, monkeypatch):
     out = cli.encode_file(str(src), "dark", 0, 0)
     blob = open(out, "rb").read()
     assert out == "book.dark" and blob[:4] == struct.pack("<I", len(data))
-    assert blob[4:] == orc.block_dc_encode("dark", data)  # single block: byte-identical to the oracle's stream
+    assert blob[4:] == orc.block_dc_encode("dark", data)  # single block: byte-identical to the oracle's stream, no footer
     assert open(cli.decode_file("book.dark", "dark", 0), "rb").read() == data
-    # multi-block extension: records are concatenated; each record alone is what a single-block run would write
+    # names follow PathBuf::set_extension (main.rs:64-66,96-98): the extension is REPLACED
+    (tmp_path / "notes.txt").write_bytes(data[:5000])
+    assert cli.encode_file(str(tmp_path / "notes.txt"), "exp") == "notes.dark"
+    assert cli.decode_file("notes.dark", "exp") == "notes.orig" and open("notes.orig", "rb").read() == data[:5000]
+    # multi-block extension (streamed + batched): records are concatenated, each is what a single-block run writes; index footer
     out = cli.encode_file(str(src), "ybs", 10000, 0)
     blob = open(out, "rb").read()
     assert blob[:4] == struct.pack("<I", 10000)
     first = orc.block_dc_encode("ybs", data[:10000])
     assert blob[4:4 + len(first)] == first
+    offsets, end = cli.read_footer(out)
+    assert len(offsets) == -(-len(data) // 10000) and offsets[1] == 4 + len(first)
+    pos = 0
+    for k, off in enumerate(offsets):  # every record, not only the first, equals the oracle's stream of that block
+        blk = data[10000 * k:10000 * (k + 1)]
+        rec = struct.pack("<I", len(blk)) + orc.block_dc_encode("ybs", blk)
+        assert off == pos and blob[off:off + len(rec)] == rec
+        pos += len(rec)
+    assert pos == end
     assert open(cli.decode_file("book.dark", "ybs", 0), "rb").read() == data
+    # the same archive without its footer decodes by walking the records (bytes consumed per record)
+    open("legacy.dark", "wb").write(blob[:end])
+    assert open(cli.decode_file("legacy.dark", "ybs", 0), "rb").read() == data
+    # two worker processes (block b -> worker b mod 2; both on GPU 0 here): identical archive, identical round trip
+    out2 = cli.encode_file(str(src), "ybs", 10000, 0, gpus=2, devices="0,0")
+    assert open(out2, "rb").read() == blob
+    assert open(cli.decode_file("book.dark", "ybs", 0, gpus=2, devices="0,0"), "rb").read() == data
     cli.main(["-m", "exp", str(src)])
     cli.main(["-m", "exp", "book.dark"])
     assert open("book.orig", "rb").read() == data
@@ -206,6 +226,49 @@ def test_cli_container(tmp_path, orc, license_bytes, monkeypatch):
     assert open("book.dark", "rb").read() == struct.pack("<I", len(data)) + b"\0\0\0\0"
     cli.encode_file(str(src), "rawdc", 0, 0)
     assert open("out-dc.raw", "rb").read() == orc.block_dc_encode("rawdc", data)
+
+
+def test_cli_constant_blocks_and_0xff(tmp_path, license_bytes, monkeypatch):
+    # a one-symbol block (zero padding in tar / disk images) inside a multi-record archive; and blocks with byte 0xFF
+    from dark_amd import cli
+    monkeypatch.chdir(tmp_path)
+    data = license_bytes * 9 + b"\0" * 8192 + license_bytes * 3 + b"\x07" * 5000
+    (tmp_path / "disk.img").write_bytes(data)
+    for model in ("dark", "exp", "ybs", "simple"):
+        out = cli.encode_file(str(tmp_path / "disk.img"), model, 4096, 0)
+        assert out == "disk.dark"
+        assert open(cli.decode_file(out, model, 0), "rb").read() == data
+        offsets, end = cli.read_footer(out)
+        open("walk.dark", "wb").write(open(out, "rb").read()[:end])  # no index: records walked by consumed bytes
+        assert open(cli.decode_file("walk.dark", model, 0), "rb").read() == data
+    (tmp_path / "bin").write_bytes(license_bytes + b"\xff" + license_bytes)
+    with pytest.raises(SystemExit) as e:
+        cli.encode_file(str(tmp_path / "bin"), "dark")
+    assert "0xFF" in str(e.value)
+    with pytest.raises(SystemExit):
+        cli.encode_file(str(tmp_path / "bin"), "dark", 700)
+    out = cli.encode_file(str(tmp_path / "bin"), "dark", force=True)  # what the reference writes, undecodable by its own format
+    with pytest.raises(dark_amd.DarkError):
+        cli.decode_file(out, "dark")
+
+
+def test_raw_block_codec(ctx, orc, license_bytes):
+    # block::raw::{Encoder,Decoder} with the dump model Out (src/block/raw.rs:35-104, src/model/raw.rs:46-76)
+    import struct
+    dump = ctx.raw_block_encode_dump(license_bytes)
+    bwt, origin = orc.bwt_forward(license_bytes)
+    assert dump == struct.pack(">I", origin) + bwt.tobytes()
+    assert ctx.raw_block_decode(b"\0\0\0\0", 10) == b"\0" * 10  # Out::decode "not supported": symbol 0 for everything
+    with pytest.raises(dark_amd.DarkError) as e:
+        ctx.raw_block_encode_dump(license_bytes, raw_model=1)     # bbb: compress::...::apm::Gate is not in the reference tree
+    assert e.value.code == dark_amd._lib.DK_E_MODEL
+    lib = dark_amd.load_library()
+    assert ctx.last_block_flags() == 0
+    ctx.block_encode("dark", b"abc\xffdef")
+    assert ctx.last_block_flags() & dark_amd._lib.DK_FLAG_HAS_FF
+    ctx.block_encode("dark", b"zzzzzz")
+    assert ctx.last_block_flags() == dark_amd._lib.DK_FLAG_SINGLE_SYMBOL
+    del lib
 
 
 def test_group_size_classes(ctx, orc):
