@@ -369,6 +369,7 @@ def main(argv=None):
     ap.add_argument("--force", action="store_true", help="write archives of blocks containing byte 0xFF (undecodable in the reference format)")
     ap.add_argument("--host-threads", type=int, default=0, help="host coding threads per GPU (default: CPU quota / gpus - 1)")
     ap.add_argument("--devices", default="", help="GPU ids of the workers, comma separated (default: device, device+1, ...)")
+    ap.add_argument("--stats", action="store_true", help="print a JSON line with the wall time of the work and the peak RSS to stderr")
     ap.add_argument("--worker", default="", help=argparse.SUPPRESS)
     ap.add_argument("--part", default="", help=argparse.SUPPRESS)
     ap.add_argument("file")
@@ -376,10 +377,19 @@ def main(argv=None):
     decode = has_extension(args.file, EXTENSION)           # main.rs:56: direction by extension
     if args.worker:
         return _worker_decode(args) if decode else _worker_encode(args)
+    import time
+    t0 = time.perf_counter()
     if decode:
-        print(decode_file(args.file, args.model, args.device, args.gpus, args.host_threads, args.devices))
+        out = decode_file(args.file, args.model, args.device, args.gpus, args.host_threads, args.devices)
     else:
-        print(encode_file(args.file, args.model, args.block_size, args.device, args.gpus, args.force, args.host_threads, args.devices))
+        out = encode_file(args.file, args.model, args.block_size, args.device, args.gpus, args.force, args.host_threads, args.devices)
+    print(out)
+    if args.stats:  # wall time of the work itself (interpreter start and imports of this front end excluded) and this process's peak RSS
+        import json
+        import resource
+        print(json.dumps({"seconds": round(time.perf_counter() - t0, 3), "input_bytes": os.path.getsize(args.file),
+                          "output_bytes": os.path.getsize(out), "peak_rss_bytes": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss * 1024}),
+              file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -25,7 +25,9 @@ def run(cmd, cwd):
     dt = time.perf_counter() - t
     if r.returncode != 0:
         sys.exit(r.stdout + r.stderr)
-    return dt, max(before, resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss) * 1024  # high-water mark of all children so far
+    inside = [json.loads(ln) for ln in r.stderr.splitlines() if ln.startswith("{")]
+    # (process wall, the CLI's own --stats line, high-water RSS mark of all children so far)
+    return dt, (inside[-1] if inside else {}), max(before, resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss) * 1024
 
 
 def sha(path):
@@ -52,14 +54,16 @@ def main():
                 datagen.wiki_like(args.block_bytes, 40 + b).tofile(f)
         total = os.path.getsize(src)
         extra = ["--gpus", str(args.gpus)] + (["--devices", args.devices] if args.devices else [])
-        cmd = [sys.executable, "-m", "dark_amd.cli", "-m", args.model, "-b", str(args.block_bytes)] + extra
-        t_enc, rss_enc = run(cmd + [src], d)
+        cmd = [sys.executable, "-m", "dark_amd.cli", "--stats", "-m", args.model, "-b", str(args.block_bytes)] + extra
+        t_enc, in_enc, rss_enc = run(cmd + [src], d)
         packed = os.path.join(d, "enwik9_like.dark")
-        t_dec, rss_dec = run([sys.executable, "-m", "dark_amd.cli", "-m", args.model] + extra + [packed], d)
+        t_dec, in_dec, rss_dec = run([sys.executable, "-m", "dark_amd.cli", "--stats", "-m", args.model] + extra + [packed], d)
         ok = sha(os.path.join(d, "enwik9_like.orig")) == sha(src)
         print(json.dumps({"file_bytes": total, "blocks": args.blocks, "block_bytes": args.block_bytes, "model": args.model, "gpus": args.gpus,
                           "encode_s": round(t_enc, 2), "encode_MBps": round(total / t_enc / 1e6, 1), "decode_s": round(t_dec, 2),
-                          "decode_MBps": round(total / t_dec / 1e6, 1), "packed_bytes": os.path.getsize(packed), "roundtrip_ok": ok,
+                          "decode_MBps": round(total / t_dec / 1e6, 1),
+                          "encode_inside": in_enc, "encode_MBps_inside": round(total / in_enc["seconds"] / 1e6, 1) if in_enc else None,
+                          "decode_inside": in_dec, "decode_MBps_inside": round(total / in_dec["seconds"] / 1e6, 1) if in_dec else None, "packed_bytes": os.path.getsize(packed), "roundtrip_ok": ok,
                           "peak_rss_bytes_children": rss_dec, "peak_rss_in_blocks": round(rss_dec / args.block_bytes, 2),
                           "note": "wall time of the whole CLI process (python start, library load, context creation, file I/O included); "
                                   "RSS includes the library's pinned staging of the distance streams (about 2.5 bytes per input byte per "
