@@ -5,7 +5,7 @@ The shared library dark_amd/libdark_amd.so (HIP kernels for gfx950 + host entrop
 CPU fallback.  Build it with `python dark_amd/build.py`."""
 from . import _lib
 from ._lib import load as load_library
-from .context import Context, DarkError
+from .context import Context, DarkError, multi_block_encode, multi_block_decode
 from . import saca, block, model, entropy
 
-__all__ = ["Context", "DarkError", "saca", "block", "model", "entropy", "load_library"]
+__all__ = ["Context", "DarkError", "multi_block_encode", "multi_block_decode", "saca", "block", "model", "entropy", "load_library"]

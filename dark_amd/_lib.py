@@ -51,6 +51,8 @@ SIGNATURES = {
     "dk_dev_block_decode": (_i, [_vp, _i, _vp, _sz, _sz, _vp]),
     "dk_dev_batch_encode": (_i, [_vp, _i, _sz, _vp, _vp, _vp, _vp, _vp, _i]),
     "dk_dev_batch_decode": (_i, [_vp, _i, _sz, _vp, _vp, _vp, _vp, _i]),
+    "dk_multi_block_encode": (_i, [_vp, _i, _i, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
+    "dk_multi_block_decode": (_i, [_vp, _i, _i, _sz, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
     "dk_model_encode": (_i, [_i, _vp, _vp, _sz, _vp, _sz, _szp]),
     "dk_model_decode": (_i, [_i, _vp, _sz, _vp, _sz, _vp]),
     "dk_bitcoder_encode": (_i, [_vp, _vp, _sz, _vp, _sz, _szp]),

@@ -247,3 +247,39 @@ class Context:
         vals = np.ascontiguousarray(vals, dtype=np.uint32).copy()
         self._ck(self._lib.dk_dbg_sort_pairs(self._h, _ptr(keys), _ptr(vals), len(keys), begin_bit, end_bit))
         return keys, vals
+
+
+def multi_block_encode(model, blocks, devices, host_threads_per_gpu=4):
+    """dk_multi_block_encode: block i -> GPU devices[i mod len(devices)], one host thread + one context per listed device inside the call"""
+    lib = _lib.load()
+    keep = [as_u8(b) for b in blocks]
+    count = len(keep)
+    outs = [np.empty(2 * len(b) + 4096, dtype=np.uint8) for b in keep]
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    ins = (C.c_void_p * count)(*[_ptr(b) for b in keep])
+    ns = (C.c_size_t * count)(*[len(b) for b in keep])
+    optrs = (C.c_void_p * count)(*[_ptr(o) for o in outs])
+    caps = (C.c_size_t * count)(*[len(o) for o in outs])
+    lens = (C.c_size_t * count)()
+    err = C.create_string_buffer(512)
+    rc = lib.dk_multi_block_encode(devs, len(devices), model_id(model), count, ins, ns, optrs, caps, lens, int(host_threads_per_gpu), err, 512)
+    if rc:
+        raise DarkError(rc, err.value.decode())
+    return [o[:lens[i]].tobytes() for i, o in enumerate(outs)]
+
+
+def multi_block_decode(model, streams, sizes, devices, host_threads_per_gpu=4):
+    lib = _lib.load()
+    keep = [as_u8(s) for s in streams]
+    count = len(keep)
+    outs = [np.empty(int(n), dtype=np.uint8) for n in sizes]
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    ins = (C.c_void_p * count)(*[_ptr(s) for s in keep])
+    lens = (C.c_size_t * count)(*[len(s) for s in keep])
+    ns = (C.c_size_t * count)(*[int(n) for n in sizes])
+    optrs = (C.c_void_p * count)(*[_ptr(o) for o in outs])
+    err = C.create_string_buffer(512)
+    rc = lib.dk_multi_block_decode(devs, len(devices), model_id(model), count, ins, lens, ns, optrs, int(host_threads_per_gpu), err, 512)
+    if rc:
+        raise DarkError(rc, err.value.decode())
+    return [o.tobytes() for o in outs]

@@ -5,6 +5,7 @@
 #include <deque>
 #include <mutex>
 #include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -32,8 +33,9 @@ int check_n(dk_ctx *ctx, size_t n) {
     return DK_OK;
 }
 size_t workspace_bytes(size_t max_n) {
-    // text copy n + bwt n + DC arrays 10 n + SA 4 n + suffix-sort temporaries 66 n + per-tile tables (< n) + slack
-    return 86 * max_n + (48u << 20);
+    // text copy n + L n + SA 4 n + suffix-sort temporaries 62 n + per-tile tables (< n) + slack; the DC arrays (10 n) and the
+    // inverse BWT's successor table (8 n) reuse the temporaries' place
+    return 70 * max_n + (48u << 20);
 }
 struct ScopedCall {
     dk_ctx *c;
@@ -56,11 +58,7 @@ struct ForwardResult {
 int forward_to_stream(dk_ctx *ctx, const uint8_t *d_text, size_t n, bool want_ctx_fields, ForwardResult *fr, int slot = -1) {
     hipStream_t st = ctx->stream;
     uint8_t *d_bwt = ctx->ws_alloc<uint8_t>(n);
-    uint32_t *d_dist = ctx->ws_alloc<uint32_t>(n);
-    uint8_t *d_sym = ctx->ws_alloc<uint8_t>(n);
-    uint8_t *d_rank = want_ctx_fields ? ctx->ws_alloc<uint8_t>(n) : nullptr;
-    uint32_t *d_run_end = want_ctx_fields ? ctx->ws_alloc<uint32_t>(n) : nullptr;
-    if (!d_bwt || !d_dist || !d_sym || (want_ctx_fields && (!d_rank || !d_run_end))) return DK_E_NOMEM;
+    if (!d_bwt) return DK_E_NOMEM;
     {
         const size_t mark = ctx->ws_mark();
         uint32_t *d_sa = ctx->ws_alloc<uint32_t>(n);
@@ -68,6 +66,12 @@ int forward_to_stream(dk_ctx *ctx, const uint8_t *d_text, size_t n, bool want_ct
         DK_TRY(bwt_forward_device(ctx, d_text, n, d_sa, d_bwt, &fr->origin));  // sets stats.ms_sa / ms_bwt
         ctx->ws_release(mark);
     }
+    // the DC arrays take the place of the suffix sort's temporaries (only L survives the sort)
+    uint32_t *d_dist = ctx->ws_alloc<uint32_t>(n);
+    uint8_t *d_sym = ctx->ws_alloc<uint8_t>(n);
+    uint8_t *d_rank = want_ctx_fields ? ctx->ws_alloc<uint8_t>(n) : nullptr;
+    uint32_t *d_run_end = want_ctx_fields ? ctx->ws_alloc<uint32_t>(n) : nullptr;
+    if (!d_dist || !d_sym || (want_ctx_fields && (!d_rank || !d_run_end))) return DK_E_NOMEM;
     Timer t3;
     DK_TRY(dc_encode_device(ctx, d_bwt, n, fr->init, d_dist, d_sym, d_rank, d_run_end, &fr->m));
     ctx->stats.ms_dc = t3.ms();
@@ -611,6 +615,103 @@ int dk_raw_block_decode(dk_ctx *ctx, int raw_model, const uint8_t *in, size_t in
     DK_TRY(check_n(ctx, n));
     std::memset(out, 0, n);  // Out::decode returns symbol 0 ("not supported", src/model/raw.rs:71-75): origin 0, a BWT of zeros -> n zeros
     return DK_OK;
+}
+
+}  // extern "C" (the helper below is a template)
+
+// ---- several GPUs in one call: one host thread + one context per listed device ---------------------------------------------------------
+namespace {
+struct DeviceBuffers {  // input / output blocks of one sub-batch in HBM
+    std::vector<uint8_t *> ptr;
+    ~DeviceBuffers() { for (uint8_t *p : ptr) if (p) (void)hipFree(p); }
+};
+template <class Work>
+int run_per_device(const int *devices, int ndev, size_t count, const size_t *n, char *err, size_t err_cap, Work work) {
+    if (!devices || ndev <= 0 || count == 0 || !n) return DK_E_ARG;
+    std::vector<int> rcs(static_cast<size_t>(ndev), DK_OK);
+    std::vector<std::string> msgs(static_cast<size_t>(ndev));
+    std::vector<std::thread> threads;
+    for (int r = 0; r < ndev; ++r) {
+        threads.emplace_back([&, r] {
+            std::vector<size_t> mine;
+            size_t max_n = 0;
+            for (size_t i = static_cast<size_t>(r); i < count; i += static_cast<size_t>(ndev)) { mine.push_back(i); max_n = std::max(max_n, n[i]); }
+            if (mine.empty()) return;
+            dk_ctx *ctx = nullptr;
+            int rc = dk_ctx_create(devices[r], max_n, &ctx);
+            if (rc != DK_OK) { rcs[r] = rc; msgs[r] = "dk_ctx_create failed on device " + std::to_string(devices[r]); return; }
+            rc = work(ctx, mine);
+            if (rc != DK_OK) { rcs[r] = rc; msgs[r] = dk_last_error(ctx); }
+            dk_ctx_destroy(ctx);
+        });
+    }
+    for (auto &t : threads) t.join();
+    for (int r = 0; r < ndev; ++r)
+        if (rcs[r] != DK_OK) {
+            if (err && err_cap) snprintf(err, err_cap, "device %d: %s", devices[r], msgs[r].c_str());
+            return rcs[r];
+        }
+    if (err && err_cap) err[0] = 0;
+    return DK_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int dk_multi_block_encode(const int *devices, int ndev, int model_id, size_t count, const uint8_t *const *in, const size_t *n, uint8_t *const *out,
+                          const size_t *out_cap, size_t *out_len, int host_threads_per_gpu, char *err, size_t err_cap) {
+    if (!in || !out || !out_cap || !out_len) return DK_E_ARG;
+    const size_t group = static_cast<size_t>(std::max(1, host_threads_per_gpu)) + 1;  // blocks resident in HBM per sub-batch
+    return run_per_device(devices, ndev, count, n, err, err_cap, [&](dk_ctx *ctx, const std::vector<size_t> &mine) -> int {
+        for (size_t lo = 0; lo < mine.size(); lo += group) {
+            const size_t cnt = std::min(group, mine.size() - lo);
+            DeviceBuffers db;
+            std::vector<const uint8_t *> d_in(cnt);
+            std::vector<size_t> ns(cnt), caps(cnt), lens(cnt);
+            std::vector<uint8_t *> outs(cnt);
+            for (size_t k = 0; k < cnt; ++k) {
+                const size_t i = mine[lo + k];
+                uint8_t *p = nullptr;
+                if (!in[i] || !out[i] || n[i] == 0) return ctx->fail(DK_E_ARG, "null pointer or empty block %zu", i);
+                if (hipMalloc(reinterpret_cast<void **>(&p), n[i]) != hipSuccess) return ctx->fail(DK_E_NOMEM, "hipMalloc of block %zu failed", i);
+                db.ptr.push_back(p);
+                if (hipMemcpy(p, in[i], n[i], hipMemcpyHostToDevice) != hipSuccess) return ctx->fail(DK_E_HIP, "upload of block %zu failed", i);
+                d_in[k] = p; ns[k] = n[i]; caps[k] = out_cap[i]; outs[k] = out[i];
+            }
+            const int rc = dk_dev_batch_encode(ctx, model_id, cnt, d_in.data(), ns.data(), outs.data(), caps.data(), lens.data(), host_threads_per_gpu);
+            if (rc != DK_OK) return rc;
+            for (size_t k = 0; k < cnt; ++k) out_len[mine[lo + k]] = lens[k];
+        }
+        return DK_OK;
+    });
+}
+
+int dk_multi_block_decode(const int *devices, int ndev, int model_id, size_t count, const uint8_t *const *in, const size_t *in_len, const size_t *n,
+                          uint8_t *const *out, int host_threads_per_gpu, char *err, size_t err_cap) {
+    if (!in || !in_len || !out) return DK_E_ARG;
+    const size_t group = static_cast<size_t>(std::max(1, host_threads_per_gpu)) + 1;
+    return run_per_device(devices, ndev, count, n, err, err_cap, [&](dk_ctx *ctx, const std::vector<size_t> &mine) -> int {
+        for (size_t lo = 0; lo < mine.size(); lo += group) {
+            const size_t cnt = std::min(group, mine.size() - lo);
+            DeviceBuffers db;
+            std::vector<const uint8_t *> ins(cnt);
+            std::vector<size_t> lens(cnt), ns(cnt);
+            std::vector<uint8_t *> d_out(cnt);
+            for (size_t k = 0; k < cnt; ++k) {
+                const size_t i = mine[lo + k];
+                uint8_t *p = nullptr;
+                if (!in[i] || !out[i] || n[i] == 0) return ctx->fail(DK_E_ARG, "null pointer or empty block %zu", i);
+                if (hipMalloc(reinterpret_cast<void **>(&p), n[i]) != hipSuccess) return ctx->fail(DK_E_NOMEM, "hipMalloc of block %zu failed", i);
+                db.ptr.push_back(p);
+                ins[k] = in[i]; lens[k] = in_len[i]; ns[k] = n[i]; d_out[k] = p;
+            }
+            const int rc = dk_dev_batch_decode(ctx, model_id, cnt, ins.data(), lens.data(), ns.data(), d_out.data(), host_threads_per_gpu);
+            if (rc != DK_OK) return rc;
+            for (size_t k = 0; k < cnt; ++k)
+                if (hipMemcpy(out[mine[lo + k]], d_out[k], ns[k], hipMemcpyDeviceToHost) != hipSuccess) return ctx->fail(DK_E_HIP, "download of block %zu failed", mine[lo + k]);
+        }
+        return DK_OK;
+    });
 }
 
 // ---- model / coder level (host only) --------------------------------------------------------------------------------------

@@ -911,13 +911,13 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
 
     uint64_t *keys = ctx->ws_alloc<uint64_t>(n), *keys_alt = ctx->ws_alloc<uint64_t>(n), *keys_3 = ctx->ws_alloc<uint64_t>(n);
     uint32_t *vals = ctx->ws_alloc<uint32_t>(n), *vals_alt = ctx->ws_alloc<uint32_t>(n);
-    uint32_t *vals_3 = ctx->ws_alloc<uint32_t>(n), *vals_4 = ctx->ws_alloc<uint32_t>(n);
+    uint32_t *vals_3 = ctx->ws_alloc<uint32_t>(n);
     uint32_t *rank = ctx->ws_alloc<uint32_t>(n);
     uint32_t *pos = ctx->ws_alloc<uint32_t>(n), *pos_alt = ctx->ws_alloc<uint32_t>(n);
     uint32_t *gid = ctx->ws_alloc<uint32_t>(n), *gid_alt = ctx->ws_alloc<uint32_t>(n);
     uint32_t *gstart = ctx->ws_alloc<uint32_t>(n / 2 + 2), *bigstart = ctx->ws_alloc<uint32_t>(n / 2 + 2);
     uint8_t *d_code = reinterpret_cast<uint8_t *>(ctx->d_mail + 512);
-    if (!keys || !keys_alt || !keys_3 || !vals || !vals_alt || !vals_3 || !vals_4 || !rank || !pos || !pos_alt || !gid || !gid_alt ||
+    if (!keys || !keys_alt || !keys_3 || !vals || !vals_alt || !vals_3 || !rank || !pos || !pos_alt || !gid || !gid_alt ||
         !gstart || !bigstart)
         return DK_E_NOMEM;
     DK_HIP(ctx, hipMemcpyAsync(d_code, code, 256, hipMemcpyHostToDevice, st));
@@ -1051,7 +1051,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
         DK_HIP(ctx, hipGetLastError());
         if (nbig > 0) {
             uint64_t *bk = keys_alt, *bk_alt = keys_3;
-            uint32_t *bv = vals_3, *bv_alt = vals_4;
+            uint32_t *bv = vals_3, *bv_alt = vals;  // the round's input list has been read (k_round_local); the rerank rewrites it below
             DK_TRY(sort_pairs(ctx, bk, bk_alt, bv, bv_alt, nbig, 0, kb + bsbits));
             {
                 LaunchScope ls(ctx, K_BIG_BACK, 28.0 * nbig);

@@ -126,6 +126,17 @@ int dk_dev_batch_decode(dk_ctx *ctx, int model_id, size_t count, const uint8_t *
 /* whole inverse path from a coded stream in host memory to a device-resident block */
 int dk_dev_block_decode(dk_ctx *ctx, int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *d_out);
 
+/* ---- several GPUs in one call ------------------------------------------------------------------------------------------------------
+ * Blocks are independent (fresh model and coder per block, src/block/dc.rs:30-37,53): block i goes to GPU devices[i mod ndev].  Inside
+ * the call every listed device gets one host thread with its own dk_ctx ("one host thread + one context per GPU",
+ * no inter-GPU traffic); each runs the pipelined batch path on its blocks with host_threads_per_gpu coding threads.  `devices` may name
+ * a GPU twice (two contexts on one GPU).  in / out are host pointers; out[i] / out_len[i] are exactly what dk_block_encode gives for
+ * block i.  err (may be NULL) receives the text of the first failure. */
+int dk_multi_block_encode(const int *devices, int ndev, int model_id, size_t count, const uint8_t *const *in, const size_t *n,
+                          uint8_t *const *out, const size_t *out_cap, size_t *out_len, int host_threads_per_gpu, char *err, size_t err_cap);
+int dk_multi_block_decode(const int *devices, int ndev, int model_id, size_t count, const uint8_t *const *in, const size_t *in_len,
+                          const size_t *n, uint8_t *const *out, int host_threads_per_gpu, char *err, size_t err_cap);
+
 /* ---- model / coder level (host; what src/model/mod.rs:59-76 and src/entropy/ari.rs:76-107 exercise) ----------- */
 /* model.reset(); for k: model.encode(dist[k], Context{symbol: sym[k]}, eh); eh.finish()   (src/model/mod.rs:59-66) */
 int dk_model_encode(int model_id, const uint32_t *dist, const uint8_t *sym, size_t m,

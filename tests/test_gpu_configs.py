@@ -97,6 +97,19 @@ def test_two_contexts_on_two_threads(orc):
     del rng
 
 
+def test_multi_gpu_entry_point(orc):
+    """dk_multi_block_encode / _decode: block i -> devices[i mod ndev], one host thread + one dk_ctx per listed device inside the call.
+    A one-GPU box lists GPU 0 twice: two contexts, two threads, the same GPU."""
+    blocks = [datagen.wiki_like(200_000 + 7777 * i, 60 + i) for i in range(5)] + [np.zeros(3000, np.uint8)]
+    streams = dark_amd.multi_block_encode("dark", blocks, devices=[0, 0], host_threads_per_gpu=2)
+    for b, s in zip(blocks, streams):
+        assert s == orc.block_dc_encode("dark", b)
+    back = dark_amd.multi_block_decode("dark", streams, [len(b) for b in blocks], devices=[0, 0], host_threads_per_gpu=2)
+    assert back == [b.tobytes() for b in blocks]
+    with pytest.raises(dark_amd.DarkError):
+        dark_amd.multi_block_encode("dark", blocks, devices=[0, 99])
+
+
 @pytest.mark.skipif(not os.environ.get("DARK_CORPUS_DIR"), reason="set DARK_CORPUS_DIR to a directory holding book1 and/or enwik8")
 def test_real_corpus_sizes():
     """README.md:20: book1 -> 214 445 B with the `dark` model (file = 4-byte header of src/main.rs:102 + stream).  The only pin the

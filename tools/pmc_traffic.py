@@ -21,9 +21,19 @@ import re
 import sys
 
 # kernels whose reads are random narrow gathers: one 64-byte request per access, FETCH_SIZE is taken as reported
-GATHER_KERNELS = {"k_round_local", "k_bwt_gather", "k_radix_scan_a", "k_radix_scan_b", "k_radix_scan_c", "k_big_reduce", "k_big_spine", "k_big_apply",
-                  "k_big_back", "k_rerank_scan", "k_dc_carry_a", "k_dc_carry_b", "k_dc_carry_c", "k_dc_runscan", "k_dc_sweep", "k_fill_u32",
-                  "k_place_active", "k_rank_active", "k_prefix_probe"}
+GATHER_KERNELS = {"k_round_local", "k_plateau_sort", "k_plateau_ranks", "k_bwt_gather", "k_radix_scan_a", "k_radix_scan_b", "k_radix_scan_c",
+                  "k_big_reduce", "k_big_spine", "k_big_apply", "k_big_back", "k_rerank_scan", "k_dc_carry_a", "k_dc_carry_b", "k_dc_carry_c",
+                  "k_dc_runscan", "k_dc_sweep", "k_fill_u32", "k_place_active", "k_rank_active", "k_prefix_probe", "k_to_inplace",
+                  "k_plateau_scan", "k_ibwt_walk", "k_ibwt_emit", "k_ibwt_jump"}
+
+# dk_stats slot (dark_amd/csrc/context.hpp) of every kernel: a slot is named after its kernel, or after the common prefix of the kernels
+# one LaunchScope brackets; bench.py reports HIP-event times per slot, the rocprofv3 CSVs are per kernel
+SLOT_OF = {"k_radix_scan_a": "k_radix_scan", "k_radix_scan_b": "k_radix_scan", "k_radix_scan_c": "k_radix_scan",
+           "k_dc_runscan": "k_dc_carry", "k_dc_carry_a": "k_dc_carry", "k_dc_carry_b": "k_dc_carry", "k_dc_carry_c": "k_dc_carry",
+           "k_fill_u32": "k_dc_carry", "k_ibwt_scan_a": "k_ibwt_hist", "k_ibwt_scan_b": "k_ibwt_hist", "k_ibwt_scan_c": "k_ibwt_hist",
+           "k_big_reduce": "k_big_classify", "k_big_spine": "k_big_classify", "k_big_apply": "k_big_classify",
+           "k_rank_active": "k_place_active", "k_to_inplace": "k_plateau_ranks", "k_plateau_count": "k_plateau_ranks",
+           "k_plateau_scan": "k_plateau_ranks", "k_plateau_compact": "k_plateau_ranks"}
 
 
 def short(name):
@@ -56,7 +66,7 @@ def main():
     ap.add_argument("write_dir")
     ap.add_argument("--steps", type=int, required=True, help="steps (warm-up + timed) the profiled command ran")
     ap.add_argument("--workload", required=True)
-    ap.add_argument("--round", type=int, default=1)
+    ap.add_argument("--round", type=int, default=2)
     args = ap.parse_args()
     fetch = collect(args.fetch_dir, "FETCH_SIZE")
     write = collect(args.write_dir, "WRITE_SIZE")
@@ -69,12 +79,19 @@ def main():
         corr = 1.0 if k in GATHER_KERNELS else 2.0
         hbm = fb * corr + wb
         total += hbm / args.steps
-        kernels[k] = {"launches_per_step": launches / args.steps, "fetch_raw_bytes_per_step": round(fb / args.steps),
+        kernels[k] = {"slot": SLOT_OF.get(k, k), "launches_per_step": launches / args.steps, "fetch_raw_bytes_per_step": round(fb / args.steps),
                       "fetch_correction": corr, "write_bytes_per_step": round(wb / args.steps),
                       "hbm_bytes_per_launch": round(hbm / launches) if launches else 0}
     kernels = dict(sorted(kernels.items(), key=lambda kv: -(kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_per_step"])))
+    # per slot, for bench.py: HBM bytes per step of all the kernels a slot brackets
+    slots = {}
+    for k, v in kernels.items():
+        e = slots.setdefault(v["slot"], {"hbm_bytes_per_step": 0, "launches_per_step": 0.0})
+        e["hbm_bytes_per_step"] += round(v["hbm_bytes_per_launch"] * v["launches_per_step"])
+        e["launches_per_step"] += v["launches_per_step"]
     json.dump({"command": "rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py "
-                          "--steps 2 --warmup 1 --no-cpu-baseline --no-decode --pipeline-blocks 0",
+                          "--workload %s --steps S --warmup W --no-cpu-baseline --no-decode --pipeline-blocks 0" % args.workload,
+               "slots": slots,
                "workload": args.workload, "round": args.round,
                "unit_note": "counter values are KiB; FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming reads on gfx950 "
                             "(MI355X_MICROARCH.md, HBM section): fetch_corrected = 2 x raw for streaming kernels, raw for random 4-byte / "
