@@ -129,9 +129,10 @@ inline unsigned ceil_log2_u64(uint64_t v) {  // smallest b with (1 << b) >= v
 
 // ---- device stages (each enqueues on ctx->stream; the ones returning host values synchronise) -------------------
 // radix_sort.hip
+// first pass of the suffix sort's initial sort straight from the text: key(i) = packed codes of T[i .. i+spk) (<< 8 | code of T[i-1])
+struct TextKeys { const uint8_t *t = nullptr; size_t n = 0; const uint8_t *code = nullptr; int bits = 0, spk = 0, with_prev = 0; };
 int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
-               int begin_bit, int end_bit);
-int sort_check_error(dk_ctx *ctx);
+               int begin_bit, int end_bit, const TextKeys *text = nullptr);
 int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, size_t count, size_t limit, uint64_t *scratch,
                          uint32_t *dst);
 // suffix_array.hip: d_sa_out may alias nothing in the workspace; d_text is caller or ctx owned

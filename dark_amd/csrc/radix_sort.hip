@@ -1,16 +1,17 @@
 // Stable LSD radix sort of (u64 key, u32 value) pairs, 8 bits per pass -- the workhorse of the suffix sort.
 // It takes the place of all the sorting work inside saca() (src/saca.rs:270-340): bucket placement, the induced
-// sorts and the naming pass become "sort by packed prefix, then by (group, rank of the suffix h further on)".
+// sorts and the naming pass become "sort by packed prefix, then by the symbols / ranks further on".
 //
-// Single-pass-per-digit path (default, count < 2^30):
-//   k_radix_hist_all one read of the keys -> the 256-bin histograms of ALL passes (LDS atomics) -> digit_base[pass][256]
-//   k_radix_scatter<true>  per pass: tiles are handed out by an atomic ticket, each tile ranks its keys stably with wave64
-//                    ballots (match-any over the 8 digit bits), publishes its per-digit counts as {flag,value} words and
-//                    finds its global offsets by decoupled look-back over the preceding tiles' words (relaxed agent-scope
-//                    atomics; the word IS the flag, so no fence is needed), reorders the tile in LDS so that equal digits
-//                    are contiguous, then writes runs to HBM.  Every spin is bounded and sets an error word.
-// Three-phase path (count >= 2^30, or DK_SORT=classic): k_radix_hist per pass -> k_radix_scan_{a,b,c} -> k_radix_scatter<false>.
-// Algorithmic bytes per pass: scatter 12 B/pair read + 12 B/pair written; hist_all 8 B/key once per sort.
+// Per pass, three phases:
+//   k_radix_hist        per-tile 256-bin digit histograms (LDS atomics over 16 private copies: text digits are skewed)
+//   k_radix_scan_a/b/c  digit-major exclusive scan of the tile histograms -> global offset of every (tile, digit)
+//   k_radix_scatter     a tile ranks its pairs stably with wave64 ballots (match-any over the 8 digit bits), reorders them in LDS so
+//                       that equal digits are contiguous, then writes runs to HBM.  XCD-aware tile order: every XCD takes one
+//                       contiguous range of tiles, so the short output runs of neighbouring tiles meet in the same L2.
+// Algorithmic bytes per pass: scatter 12 B/pair read + 12 B/pair written; histogram 8 B/key.
+// (Two single-kernel-per-pass variants with decoupled look-back -- global ticket order, and per-XCD chunks with the next pass's
+// histograms accumulated while scattering -- were built and measured in round 1: 2.2 TB/s and 1.04 ms per pass of 1e8 pairs against
+// 0.81 ms for these three phases.  They lost and were removed; DESIGN.md section 4.1 keeps the numbers.)
 #include "context.hpp"
 #include <cstdlib>
 #include <string>
@@ -20,10 +21,16 @@
 namespace dk {
 namespace {
 
-constexpr int RS_BLOCK = 256;
+#ifndef DK_RS_BLOCK
+#define DK_RS_BLOCK 256
+#endif
+constexpr int RS_BLOCK = DK_RS_BLOCK;        // threads per workgroup.  512 (8192-pair tiles, twice as long output runs) was measured
+                                             // in round 2: no faster on uniform digits (ACGT 8.9 ms either way), slower on text (5.5
+                                             // against 4.3 ms) -- the scatter is not short of coalescing, it sits at 76 % of the copy rate
 constexpr int RS_WAVES = RS_BLOCK / 64;
 constexpr int RS_KPT = 16;                   // pairs per thread
 constexpr int RS_TILE = RS_BLOCK * RS_KPT;   // 4096 pairs per workgroup
+constexpr int RS_TEXT_AHEAD = 64 + 16;       // TextKeys: codes staged beyond the tile (spk <= 64)
 constexpr int RS_MAX_CHUNKS = 256;
 
 __device__ __forceinline__ uint32_t digit_of(uint64_t k, int shift) { return static_cast<uint32_t>(k >> shift) & 0xFFu; }
@@ -36,22 +43,67 @@ __device__ __forceinline__ uint64_t load_key(const uint64_t *__restrict__ keys, 
     return keys[i];
 }
 
+// ---- first pass straight from the text -------------------------------------------------------------------------------------------
+// The initial sort of the suffix sort needs no key array to start with: the key of position i is the packed codes of T[i .. i+spk)
+// (shifted up one byte with the code of T[i-1] below when with_prev), its value is i.  The first pass's histogram and scatter
+// kernels build the keys of their tile in LDS from n bytes of text instead of reading 12 n bytes of (key, index) pairs that a
+// separate kernel would have had to write first.
+template <class Sink>  // sink(position inside the tile, key)
+__device__ __forceinline__ void text_tile_keys(const TextKeys &tk, size_t b0, uint8_t *s_code, uint8_t *s_c, Sink &&sink) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 256; i += RS_BLOCK) s_code[i] = tk.code[i];
+    __syncthreads();
+    if (tid == 0) s_c[RS_TILE + RS_TEXT_AHEAD] = s_code[tk.t[b0 ? b0 - 1 : tk.n - 1]];  // code of the symbol in front of the tile
+    const bool aligned = (reinterpret_cast<uintptr_t>(tk.t) & 15) == 0;
+    for (int o = tid * 16; o < RS_TILE + RS_TEXT_AHEAD; o += RS_BLOCK * 16) {
+        const size_t p = b0 + o;
+        uint8_t raw[16];
+        if (aligned && p + 16 <= tk.n) {
+            *reinterpret_cast<uint4 *>(raw) = *reinterpret_cast<const uint4 *>(tk.t + p);
+#pragma unroll
+            for (int b = 0; b < 16; ++b) raw[b] = s_code[raw[b]];
+        } else {
+#pragma unroll
+            for (int b = 0; b < 16; ++b) raw[b] = (p + b < tk.n) ? s_code[tk.t[p + b]] : 0;  // zero padding past the end of the text
+        }
+        *reinterpret_cast<uint4 *>(s_c + o) = *reinterpret_cast<const uint4 *>(raw);
+    }
+    __syncthreads();
+    const int base = tid * RS_KPT;  // RS_KPT consecutive positions per thread: a sliding window over the codes
+    const int bits = tk.bits, spk = tk.spk;
+    const uint64_t mask = (spk * bits >= 64) ? ~0ull : ((1ull << (spk * bits)) - 1ull);
+    uint64_t key = 0;
+    for (int j = 0; j < spk; ++j) key = (key << bits) | s_c[base + j];
+#pragma unroll
+    for (int g = 0; g < RS_KPT; ++g) {
+        if (g) key = ((key << bits) | s_c[base + spk + g - 1]) & mask;
+        uint64_t out = key;
+        if (tk.with_prev) out = (key << 8) | (base + g ? s_c[base + g - 1] : s_c[RS_TILE + RS_TEXT_AHEAD]);
+        sink(base + g, out);
+    }
+}
+
 // 16 private copies of the histogram (copy = lane mod 16): text digits are skewed, and LDS atomics of one wave instruction that
 // hit the same address are serialised; spreading them over copies cuts that contention up to 16 x.
 constexpr int RS_HCOPIES = 16;
 
-template <bool PAIRS>
+template <bool PAIRS, bool TEXT = false>
 __global__ __launch_bounds__(RS_BLOCK) void k_radix_hist(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ hi,
                                                           const uint32_t *__restrict__ lo, size_t n, int shift,
-                                                          uint32_t *__restrict__ tile_hist) {
+                                                          uint32_t *__restrict__ tile_hist, TextKeys tk) {
     __shared__ uint32_t h[RS_HCOPIES][256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_c[TEXT ? RS_TILE + RS_TEXT_AHEAD + 16 : 16];
+    __shared__ uint8_t s_code[TEXT ? 256 : 4];
     const int tid = threadIdx.x;
-#pragma unroll
-    for (int c = 0; c < RS_HCOPIES; ++c) h[c][tid] = 0;
+    for (int i = tid; i < RS_HCOPIES * 256; i += RS_BLOCK) (&h[0][0])[i] = 0;
     __syncthreads();
     uint32_t *mine = h[tid & (RS_HCOPIES - 1)];
     const size_t base = static_cast<size_t>(blockIdx.x) * RS_TILE;
-    if (!PAIRS && base + RS_TILE <= n) {  // full tile: two keys per 16-byte load (order inside the tile is irrelevant here)
+    if (TEXT) {
+        text_tile_keys(tk, base, s_code, s_c, [&](int o, uint64_t key) {
+            if (base + o < n) atomicAdd(&mine[digit_of(key, shift)], 1u);
+        });
+    } else if (!PAIRS && base + RS_TILE <= n) {  // full tile: two keys per 16-byte load (order inside the tile is irrelevant here)
         const uint4 *p = reinterpret_cast<const uint4 *>(keys + base);
 #pragma unroll
         for (int k = 0; k < RS_KPT / 2; ++k) {
@@ -68,10 +120,12 @@ __global__ __launch_bounds__(RS_BLOCK) void k_radix_hist(const uint64_t *__restr
         }
     }
     __syncthreads();
-    uint32_t sum = 0;
+    if (tid < 256) {
+        uint32_t sum = 0;
 #pragma unroll
-    for (int c = 0; c < RS_HCOPIES; ++c) sum += h[c][tid];
-    tile_hist[static_cast<size_t>(blockIdx.x) * 256 + tid] = sum;
+        for (int c = 0; c < RS_HCOPIES; ++c) sum += h[c][tid];
+        tile_hist[static_cast<size_t>(blockIdx.x) * 256 + tid] = sum;
+    }
 }
 
 // phase A: per chunk of tiles, per digit: sum of the tile counts
@@ -132,75 +186,43 @@ __global__ __launch_bounds__(256) void k_radix_scan_c(uint32_t *__restrict__ til
     }
 }
 
-// histograms of every pass in one read of the keys
-__global__ __launch_bounds__(RS_BLOCK) void k_radix_hist_all(const uint64_t *__restrict__ keys, size_t n, int begin_bit, int npasses,
-                                                              uint32_t *__restrict__ hist) {
-    __shared__ uint32_t h[8 * 256];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < npasses * 256; i += RS_BLOCK) h[i] = 0;
-    __syncthreads();
-    const size_t stride = static_cast<size_t>(gridDim.x) * RS_BLOCK;
-    for (size_t i = static_cast<size_t>(blockIdx.x) * RS_BLOCK + tid; i < n; i += stride) {
-        const uint64_t k = keys[i] >> begin_bit;
-        for (int p = 0; p < npasses; ++p) atomicAdd(&h[p * 256 + (static_cast<uint32_t>(k >> (8 * p)) & 0xFFu)], 1u);
-    }
-    __syncthreads();
-    for (int i = tid; i < npasses * 256; i += RS_BLOCK)
-        if (h[i]) atomicAdd(&hist[i], h[i]);
-}
-// one workgroup per pass: counts -> exclusive digit starts
-__global__ __launch_bounds__(256) void k_radix_base_scan(uint32_t *__restrict__ hist) {
-    __shared__ uint32_t s_tmp[RS_WAVES + 1];
-    uint32_t *row = hist + static_cast<size_t>(blockIdx.x) * 256;
-    const uint32_t v = row[threadIdx.x];
-    row[threadIdx.x] = block_excl_sum<RS_WAVES>(v, s_tmp, nullptr);
-}
-
-__global__ void k_radix_fold_err(const uint32_t *__restrict__ err, uint32_t *__restrict__ acc) {
-    if (*err) *acc = 1;
-}
-
-constexpr uint32_t ST_LOCAL = 1u << 30, ST_INCL = 2u << 30, ST_MASK = (1u << 30) - 1;
-constexpr uint32_t RS_SPIN_LIMIT = 1u << 22;
-
-// LOOKBACK = false: tile = blockIdx.x, offsets come from the scanned tile_offs table.
-// LOOKBACK = true : tile = atomic ticket, `tile_offs` is the status array [ntiles][256] (zeroed), `digit_base` the
-//                   exclusive digit starts of this pass, ctrl[0] the ticket counter, ctrl[1] the error word.
-template <bool LOOKBACK, bool PAIRS = false>
+// tile_offs: the scanned per-tile digit offsets.  xcd_tiles != 0: XCD-aware tile order over a grid of 8 * ceil(ntiles / 8) blocks.
+template <bool PAIRS = false, bool TEXT = false>
 __global__ __launch_bounds__(RS_BLOCK) void k_radix_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                              const uint32_t *__restrict__ pair_lo,
                                                              uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n,
-                                                             int shift, uint32_t *__restrict__ tile_offs,
-                                                             const uint32_t *__restrict__ digit_base, uint32_t *__restrict__ ctrl,
-                                                             uint32_t xcd_tiles) {
-    __shared__ uint64_t s_keys[RS_TILE];          // 32 KiB: tile of keys in digit order; reused for the values
-    __shared__ uint32_t s_cnt[RS_WAVES][256];     // per-wave digit counters, then exclusive over waves
-    __shared__ uint32_t s_start[256];             // tile-local start of each digit
-    __shared__ uint32_t s_gbase[256];             // global offset of the digit minus its tile-local start
+                                                             int shift, const uint32_t *__restrict__ tile_offs, uint32_t xcd_tiles,
+                                                             TextKeys tk) {
+    __shared__ uint64_t s_keys[RS_TILE];          // tile of keys in digit order; reused for the values
+    // per-wave digit counters (then exclusive over waves) | tile-local start of each digit | global offset of the digit minus its
+    // tile-local start.  TEXT: the same 6 KiB first hold the staged codes of the tile (the counters are cleared afterwards).
+    __shared__ __attribute__((aligned(16))) uint32_t s_tab[RS_WAVES * 256 + 512];
     __shared__ uint32_t s_tmp[RS_WAVES + 1];
-    __shared__ uint32_t s_ticket;
-    __shared__ uint32_t s_hist[256];              // LOOKBACK: tile histogram made before the ranking, published early
+    __shared__ uint8_t s_code[TEXT ? 256 : 4];
+    static_assert(!TEXT || sizeof(uint32_t) * (RS_WAVES * 256 + 512) >= RS_TILE + RS_TEXT_AHEAD + 16, "code staging does not fit");
+    uint32_t (*s_cnt)[256] = reinterpret_cast<uint32_t (*)[256]>(s_tab);
+    uint32_t *s_start = s_tab + RS_WAVES * 256;
+    uint32_t *s_gbase = s_start + 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t tile = blockIdx.x;
-    if (!LOOKBACK && xcd_tiles) {
+    if (xcd_tiles) {
         // XCD-aware order: blocks b and b+8 share an XCD (round-robin dispatch, speed only); give every XCD one contiguous
         // range of tiles so that neighbouring output runs meet in the same L2.  Grid = 8 * ceil(ntiles / 8).
         const uint32_t per = gridDim.x / 8;
         tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
         if (tile >= xcd_tiles) return;
     }
-    if (LOOKBACK) {  // tickets: a tile only ever waits for tiles that already started
-        if (tid == 0) s_ticket = atomicAdd(&ctrl[0], 1u);
-        __syncthreads();
-        tile = s_ticket;
-    }
     const size_t tile_base = static_cast<size_t>(tile) * RS_TILE;
     const size_t left = n - tile_base;
     const uint32_t valid = left < static_cast<size_t>(RS_TILE) ? static_cast<uint32_t>(left) : RS_TILE;
 
-    for (int i = tid; i < RS_WAVES * 256; i += RS_BLOCK) (&s_cnt[0][0])[i] = 0;
-    if (LOOKBACK) s_hist[tid] = 0;
-    __syncthreads();
+    if (TEXT) {  // keys of the tile, in position order
+        text_tile_keys(tk, tile_base, s_code, reinterpret_cast<uint8_t *>(s_tab), [&](int o, uint64_t key) { s_keys[o] = key; });
+        __syncthreads();
+    } else {
+        for (int i = tid; i < RS_WAVES * 256; i += RS_BLOCK) s_tab[i] = 0;
+        __syncthreads();
+    }
 
     // wave w owns pairs [w*1024, (w+1)*1024) of the tile, lane-striped so that loads coalesce
     uint64_t key[RS_KPT];
@@ -210,21 +232,17 @@ __global__ __launch_bounds__(RS_BLOCK) void k_radix_scatter(const uint64_t *__re
     for (int k = 0; k < RS_KPT; ++k) {
         const uint32_t li = wbase + k * 64 + lane;
         if (li < valid) {
-            key[k] = load_key<PAIRS>(kin, vin, pair_lo, tile_base + li);  // PAIRS: vin holds the high words
-            val[k] = PAIRS ? 0u : vin[tile_base + li];
-            if (LOOKBACK) atomicAdd(&s_hist[digit_of(key[k], shift)], 1u);
+            key[k] = TEXT ? s_keys[li] : load_key<PAIRS>(kin, vin, pair_lo, tile_base + li);  // PAIRS: vin holds the high words
+            val[k] = TEXT ? static_cast<uint32_t>(tile_base + li) : (PAIRS ? 0u : vin[tile_base + li]);
         } else {
             key[k] = ~0ull;  // padding sorts behind every real pair of the tile and is never written
             val[k] = 0;
         }
     }
-    __syncthreads();
-    uint32_t *mine = nullptr;
-    uint32_t my_cnt = 0;
-    if (LOOKBACK) {  // publish this tile's counts before the (long) ranking so that successors rarely wait
-        my_cnt = s_hist[tid];
-        mine = tile_offs + static_cast<size_t>(tile) * 256 + tid;
-        __hip_atomic_store(mine, (tile == 0 ? ST_INCL : ST_LOCAL) | my_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (TEXT) {  // the codes have been consumed: their place becomes the digit counters
+        __syncthreads();
+        for (int i = tid; i < RS_WAVES * 256; i += RS_BLOCK) s_tab[i] = 0;
+        __syncthreads();
     }
 
     // stable rank inside the wave: lanes holding the same digit find each other with 8 ballots
@@ -249,43 +267,24 @@ __global__ __launch_bounds__(RS_BLOCK) void k_radix_scatter(const uint64_t *__re
     }
     __syncthreads();
 
-    {   // one thread per digit: exclusive over waves, then exclusive over digits
-        const int d = tid;
-        uint32_t run = 0;
+    {   // threads 0..255, one per digit: exclusive over waves, then (all threads take part in the scan) exclusive over digits
+        const int d = tid & 255;
+        const bool owner = tid < 256;
+        uint32_t run = 0, goff = 0;
+        if (owner) {
 #pragma unroll
-        for (int w = 0; w < RS_WAVES; ++w) {
-            const uint32_t c = s_cnt[w][d];
-            s_cnt[w][d] = run;
-            run += c;
-        }
-        uint32_t goff;
-        if (LOOKBACK) {
-            // (padding keys of the last tile were never counted in s_hist: they are not real pairs)
-            const uint32_t cnt = my_cnt;
-            uint32_t excl = 0;
-            if (tile != 0) {
-                const uint32_t *look = mine - 256;
-                uint32_t spins = 0;
-                for (;;) {
-                    const uint32_t v = __hip_atomic_load(look, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((v >> 30) == 0) {  // predecessor has not published yet
-                        if (++spins > RS_SPIN_LIMIT) { ctrl[1] = 1; break; }
-                        __builtin_amdgcn_s_sleep(1);
-                        continue;
-                    }
-                    excl += v & ST_MASK;
-                    if (v & ST_INCL) break;
-                    look -= 256;
-                }
-                __hip_atomic_store(mine, ST_INCL | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int w = 0; w < RS_WAVES; ++w) {
+                const uint32_t c = s_cnt[w][d];
+                s_cnt[w][d] = run;
+                run += c;
             }
-            goff = digit_base[d] + excl;
-        } else {
             goff = tile_offs[static_cast<size_t>(tile) * 256 + d];
         }
         const uint32_t start = block_excl_sum<RS_WAVES>(run, s_tmp, nullptr);
-        s_start[d] = start;
-        s_gbase[d] = goff - start;
+        if (owner) {
+            s_start[d] = start;
+            s_gbase[d] = goff - start;
+        }
     }
     __syncthreads();
 
@@ -319,212 +318,12 @@ __global__ __launch_bounds__(RS_BLOCK) void k_radix_scatter(const uint64_t *__re
     }
 }
 
-
-// ---- chunked single-kernel passes (DK_SORT=chunked) -------------------------------------------------------------------
-// The tiles are cut into RS_NCH = 8 contiguous chunks, one per XCD group (blocks b with equal b mod 8; observed placement, speed
-// only).  Inside a chunk tiles are handed out by a ticket and find their offsets by decoupled look-back over the chunk's earlier
-// tiles only; what precedes the chunk comes from per-chunk digit histograms H[chunk][digit], which the previous pass accumulates
-// while it scatters (every element knows its destination, hence its chunk in the next pass) -- so a pass is ONE kernel: no
-// per-pass histogram read, no scan kernels, and neighbouring output runs still meet in one XCD's L2.
-constexpr int RS_NCH = 8;
-
-struct ChunkGeom {
-    uint32_t ntiles, tiles_per_chunk;
-    uint64_t div_magic;  // ceil(2^40 / tiles_per_chunk): (x * magic) >> 40 == x / tiles_per_chunk for x < 2^20
-};
-__device__ __forceinline__ uint32_t chunk_of_tile(uint32_t tile, const ChunkGeom &g) {
-    return static_cast<uint32_t>((static_cast<uint64_t>(tile) * g.div_magic) >> 40);
-}
-
-// H[chunk][digit] of the input arrangement for the first pass
-__global__ __launch_bounds__(RS_BLOCK) void k_chunk_hist(const uint64_t *__restrict__ keys, size_t n, int shift, ChunkGeom g,
-                                                          uint32_t *__restrict__ H) {
-    __shared__ uint32_t h[RS_HCOPIES][256];
-    const int tid = threadIdx.x;
-    const uint32_t c = blockIdx.x % RS_NCH, lb = blockIdx.x / RS_NCH, nb = gridDim.x / RS_NCH;
-#pragma unroll
-    for (int k = 0; k < RS_HCOPIES; ++k) h[k][tid] = 0;
-    __syncthreads();
-    uint32_t *mine = h[tid & (RS_HCOPIES - 1)];
-    const uint32_t t0 = c * g.tiles_per_chunk;
-    const uint32_t t1 = t0 + g.tiles_per_chunk < g.ntiles ? t0 + g.tiles_per_chunk : g.ntiles;
-    for (uint32_t t = t0 + lb; t < t1; t += nb) {
-        const size_t base = static_cast<size_t>(t) * RS_TILE;
-#pragma unroll
-        for (int k = 0; k < RS_KPT; ++k) {
-            const size_t i = base + static_cast<size_t>(k) * RS_BLOCK + tid;
-            if (i < n) atomicAdd(&mine[digit_of(keys[i], shift)], 1u);
-        }
-    }
-    __syncthreads();
-    uint32_t sum = 0;
-#pragma unroll
-    for (int k = 0; k < RS_HCOPIES; ++k) sum += h[k][tid];
-    if (sum) atomicAdd(&H[c * 256 + tid], sum);
-}
-
-// ctrl[0..7] = tickets per chunk, ctrl[8] = error word; status rows follow at ctrl + 64
-__global__ __launch_bounds__(RS_BLOCK) void k_radix_chunked(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
-                                                             uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n, int shift,
-                                                             int next_shift, ChunkGeom g, const uint32_t *__restrict__ H_cur,
-                                                             uint32_t *__restrict__ H_next, uint32_t *__restrict__ ctrl) {
-    __shared__ uint64_t s_keys[RS_TILE];
-    __shared__ uint32_t s_cnt[RS_WAVES][256];
-    __shared__ uint32_t s_start[256];
-    __shared__ uint32_t s_gbase[256];
-    __shared__ uint32_t s_cbase[256];            // global start of (this chunk, digit)
-    __shared__ uint32_t s_hist[256];
-    __shared__ uint32_t s_hnext[RS_NCH][256];    // next pass: counts per (destination chunk, next digit), flushed once
-    __shared__ uint32_t s_tmp[RS_WAVES + 1];
-    __shared__ uint32_t s_ticket;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t c = blockIdx.x % RS_NCH;
-    uint32_t *status = ctrl + 64;
-    const uint32_t t0 = c * g.tiles_per_chunk;
-    if (t0 >= g.ntiles) return;
-    const uint32_t tiles_here = (t0 + g.tiles_per_chunk < g.ntiles ? t0 + g.tiles_per_chunk : g.ntiles) - t0;
-    {   // where this chunk's share of every digit starts
-        uint32_t tot = 0, before = 0;
-#pragma unroll
-        for (int cc = 0; cc < RS_NCH; ++cc) {
-            const uint32_t v = H_cur[cc * 256 + tid];
-            if (static_cast<uint32_t>(cc) < c) before += v;
-            tot += v;
-        }
-        s_cbase[tid] = block_excl_sum<RS_WAVES>(tot, s_tmp, nullptr) + before;
-#pragma unroll
-        for (int cc = 0; cc < RS_NCH; ++cc) s_hnext[cc][tid] = 0;
-    }
-    const uint64_t lt = lanemask_lt(lane);
-    const uint32_t wbase = static_cast<uint32_t>(wave) * (64 * RS_KPT);
-    for (;;) {
-        __syncthreads();  // previous tile fully written out; LDS reusable
-        if (tid == 0) s_ticket = atomicAdd(&ctrl[c], 1u);
-        for (int i = tid; i < RS_WAVES * 256; i += RS_BLOCK) (&s_cnt[0][0])[i] = 0;
-        s_hist[tid] = 0;
-        __syncthreads();
-        const uint32_t ticket = s_ticket;
-        if (ticket >= tiles_here) break;
-        const uint32_t tile = t0 + ticket;
-        const size_t tile_base = static_cast<size_t>(tile) * RS_TILE;
-        const size_t left = n - tile_base;
-        const uint32_t valid = left < static_cast<size_t>(RS_TILE) ? static_cast<uint32_t>(left) : RS_TILE;
-        uint64_t key[RS_KPT];
-        uint32_t val[RS_KPT];
-#pragma unroll
-        for (int k = 0; k < RS_KPT; ++k) {
-            const uint32_t li = wbase + k * 64 + lane;
-            if (li < valid) {
-                key[k] = kin[tile_base + li];
-                val[k] = vin[tile_base + li];
-                atomicAdd(&s_hist[digit_of(key[k], shift)], 1u);
-            } else {
-                key[k] = ~0ull;
-                val[k] = 0;
-            }
-        }
-        __syncthreads();
-        const uint32_t my_cnt = s_hist[tid];
-        uint32_t *mine = status + static_cast<size_t>(tile) * 256 + tid;
-        __hip_atomic_store(mine, (ticket == 0 ? ST_INCL : ST_LOCAL) | my_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // look back over the earlier tiles of THIS chunk only (its first tile publishes INCL at once), BEFORE the long ranking:
-        // the sooner the inclusive word is out, the shorter everybody else's walk
-        uint32_t excl = 0;
-        if (ticket != 0) {
-            const uint32_t *look = mine - 256;
-            uint32_t spins = 0;
-            for (;;) {
-                const uint32_t v = __hip_atomic_load(look, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((v >> 30) == 0) {
-                    if (++spins > RS_SPIN_LIMIT) { ctrl[8] = 1; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
-                }
-                excl += v & ST_MASK;
-                if (v & ST_INCL) break;
-                look -= 256;
-            }
-            __hip_atomic_store(mine, ST_INCL | (excl + my_cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-
-        uint32_t rnk[RS_KPT];
-#pragma unroll
-        for (int k = 0; k < RS_KPT; ++k) {
-            const uint32_t d = digit_of(key[k], shift);
-            uint64_t same = ~0ull;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bool bit = (d >> b) & 1u;
-                const uint64_t bal = __ballot(bit);
-                same &= bit ? bal : ~bal;
-            }
-            const uint32_t before = static_cast<uint32_t>(__popcll(same & lt));
-            const uint32_t old = s_cnt[wave][d];
-            __builtin_amdgcn_wave_barrier();
-            if (before == 0) s_cnt[wave][d] = old + static_cast<uint32_t>(__popcll(same));
-            __builtin_amdgcn_wave_barrier();
-            rnk[k] = old + before;
-        }
-        __syncthreads();
-        {
-            const int d = tid;
-            uint32_t run = 0;
-#pragma unroll
-            for (int w = 0; w < RS_WAVES; ++w) {
-                const uint32_t cc = s_cnt[w][d];
-                s_cnt[w][d] = run;
-                run += cc;
-            }
-            const uint32_t start = block_excl_sum<RS_WAVES>(run, s_tmp, nullptr);
-            s_start[d] = start;
-            s_gbase[d] = s_cbase[d] + excl - start;
-        }
-        __syncthreads();
-        uint32_t pos[RS_KPT];
-#pragma unroll
-        for (int k = 0; k < RS_KPT; ++k) {
-            const uint32_t d = digit_of(key[k], shift);
-            pos[k] = s_start[d] + s_cnt[wave][d] + rnk[k];
-            s_keys[pos[k]] = key[k];
-        }
-        __syncthreads();
-        uint32_t gi[RS_KPT];
-#pragma unroll
-        for (int k = 0; k < RS_KPT; ++k) {
-            const uint32_t p = k * RS_BLOCK + tid;
-            const uint64_t kk = s_keys[p];
-            gi[k] = s_gbase[digit_of(kk, shift)] + p;
-            if (p < valid) {
-                kout[gi[k]] = kk;
-                if (next_shift >= 0) atomicAdd(&s_hnext[chunk_of_tile(gi[k] / RS_TILE, g)][digit_of(kk, next_shift)], 1u);
-            }
-        }
-        __syncthreads();
-        uint32_t *s_vals = reinterpret_cast<uint32_t *>(s_keys);
-#pragma unroll
-        for (int k = 0; k < RS_KPT; ++k) s_vals[pos[k]] = val[k];
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < RS_KPT; ++k) {
-            const uint32_t p = k * RS_BLOCK + tid;
-            if (p < valid) vout[gi[k]] = s_vals[p];
-        }
-    }
-    if (next_shift >= 0) {
-#pragma unroll
-        for (int cc = 0; cc < RS_NCH; ++cc) {
-            const uint32_t v = s_hnext[cc][tid];
-            if (v) atomicAdd(&H_next[cc * 256 + tid], v);
-        }
-    }
-}
-
 }  // namespace
 
 // Sorts `count` pairs on key bits [begin_bit, end_bit).  keys/vals are the input buffers, *_alt equally sized scratch;
 // on return `keys` and `vals` refer to whichever buffer holds the sorted data (the references are swapped per pass).
 static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
-                              int begin_bit, int end_bit) {
+                              int begin_bit, int end_bit, const TextKeys *text) {
     const size_t ntiles = div_up(count, RS_TILE);
     const size_t tiles_per_chunk = div_up(ntiles, RS_MAX_CHUNKS);
     const size_t nchunks = div_up(ntiles, tiles_per_chunk);
@@ -535,8 +334,11 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
     hipStream_t st = ctx->stream;
     for (int shift = begin_bit; shift < end_bit; shift += 8) {
         {
-            LaunchScope ls(ctx, K_RADIX_HIST, 8.0 * count);
-            k_radix_hist<false><<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(keys, nullptr, nullptr, count, shift, tile_hist);
+            LaunchScope ls(ctx, K_RADIX_HIST, (text && shift == begin_bit ? 1.0 : 8.0) * count);
+            if (text && shift == begin_bit)
+                k_radix_hist<false, true><<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(nullptr, nullptr, nullptr, count, shift, tile_hist, *text);
+            else
+                k_radix_hist<false><<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(keys, nullptr, nullptr, count, shift, tile_hist, TextKeys{});
         }
         {
             LaunchScope ls(ctx, K_RADIX_SCAN, 3.0 * 1024.0 * ntiles);
@@ -545,11 +347,15 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
             k_radix_scan_c<<<dim3(nchunks), dim3(256), 0, st>>>(tile_hist, ntiles, tiles_per_chunk, chunk_sum);
         }
         {
-            LaunchScope ls(ctx, K_RADIX_SCATTER, 24.0 * count);
+            LaunchScope ls(ctx, K_RADIX_SCATTER, (text && shift == begin_bit ? 13.0 : 24.0) * count);
             static const bool xcd = [] { const char *e = getenv("DK_XCD"); return !(e && e[0] == '0'); }();
             const size_t grid = xcd ? 8 * div_up(ntiles, 8) : ntiles;
-            k_radix_scatter<false><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(keys, vals, nullptr, keys_alt, vals_alt, count, shift, tile_hist,
-                                                                         nullptr, nullptr, xcd ? static_cast<uint32_t>(ntiles) : 0u);
+            if (text && shift == begin_bit)
+                k_radix_scatter<false, true><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(nullptr, nullptr, nullptr, keys_alt, vals_alt, count, shift, tile_hist,
+                                                                                   xcd ? static_cast<uint32_t>(ntiles) : 0u, *text);
+            else
+                k_radix_scatter<false><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(keys, vals, nullptr, keys_alt, vals_alt, count, shift, tile_hist,
+                                                                             xcd ? static_cast<uint32_t>(ntiles) : 0u, TextKeys{});
         }
         DK_HIP(ctx, hipGetLastError());
         std::swap(keys, keys_alt);
@@ -561,95 +367,14 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
     return DK_OK;
 }
 
-static int sort_pairs_onesweep(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
-                               int begin_bit, int end_bit) {
-    const size_t ntiles = div_up(count, RS_TILE);
-    const int npasses = (end_bit - begin_bit + 7) / 8;
-    const size_t mark = ctx->ws_mark();
-    // ctrl words (ticket, error) sit in front of the status rows so that one memset clears both
-    uint32_t *digit_base = ctx->ws_alloc<uint32_t>(static_cast<size_t>(npasses) * 256);
-    uint32_t *ctrl = ctx->ws_alloc<uint32_t>(64 + ntiles * 256);
-    if (!digit_base || !ctrl) return DK_E_NOMEM;
-    uint32_t *status = ctrl + 64;
-    uint32_t *d_err = ctx->d_mail + 12;
-    hipStream_t st = ctx->stream;
-    DK_HIP(ctx, hipMemsetAsync(digit_base, 0, static_cast<size_t>(npasses) * 256 * sizeof(uint32_t), st));
-    {
-        LaunchScope ls(ctx, K_RADIX_HIST, 8.0 * count);
-        const size_t blocks = std::min<size_t>(div_up(count, RS_BLOCK * 8), 2048);
-        k_radix_hist_all<<<dim3(blocks), dim3(RS_BLOCK), 0, st>>>(keys, count, begin_bit, npasses, digit_base);
-        k_radix_base_scan<<<dim3(npasses), dim3(256), 0, st>>>(digit_base);
-    }
-    for (int p = 0; p < npasses; ++p) {
-        DK_HIP(ctx, hipMemsetAsync(ctrl, 0, (64 + ntiles * 256) * sizeof(uint32_t), st));
-        {
-            LaunchScope ls(ctx, K_RADIX_SCATTER, 24.0 * count);
-            k_radix_scatter<true><<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(keys, vals, nullptr, keys_alt, vals_alt, count, begin_bit + 8 * p,
-                                                                          status, digit_base + p * 256, ctrl, 0u);
-        }
-        DK_HIP(ctx, hipGetLastError());
-        // fold the error word of this pass into the mailbox (checked once per suffix sort / debug call)
-        k_radix_fold_err<<<dim3(1), dim3(1), 0, st>>>(ctrl + 1, d_err);
-        std::swap(keys, keys_alt);
-        std::swap(vals, vals_alt);
-        ctx->stats.sort_passes += 1;
-        ctx->stats.sorted_elements += count;
-    }
-    ctx->ws_release(mark);
-    return DK_OK;
-}
-
-static int sort_pairs_chunked(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
-                              int begin_bit, int end_bit) {
-    const size_t ntiles = div_up(count, RS_TILE);
-    const int npasses = (end_bit - begin_bit + 7) / 8;
-    ChunkGeom g;
-    g.ntiles = static_cast<uint32_t>(ntiles);
-    g.tiles_per_chunk = static_cast<uint32_t>(div_up(ntiles, RS_NCH));
-    g.div_magic = ((1ull << 40) + g.tiles_per_chunk - 1) / g.tiles_per_chunk;
-    const size_t mark = ctx->ws_mark();
-    uint32_t *H = ctx->ws_alloc<uint32_t>(static_cast<size_t>(npasses + 1) * RS_NCH * 256);
-    uint32_t *ctrl = ctx->ws_alloc<uint32_t>(64 + ntiles * 256);
-    if (!H || !ctrl) return DK_E_NOMEM;
-    uint32_t *d_err = ctx->d_mail + 12;
-    hipStream_t st = ctx->stream;
-    DK_HIP(ctx, hipMemsetAsync(H, 0, static_cast<size_t>(npasses + 1) * RS_NCH * 256 * sizeof(uint32_t), st));
-    const size_t grid = RS_NCH * std::min<size_t>(div_up(ntiles, RS_NCH), 160);
-    {
-        LaunchScope ls(ctx, K_RADIX_HIST, 8.0 * count);
-        k_chunk_hist<<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(keys, count, begin_bit, g, H);
-    }
-    for (int p = 0; p < npasses; ++p) {
-        DK_HIP(ctx, hipMemsetAsync(ctrl, 0, (64 + ntiles * 256) * sizeof(uint32_t), st));
-        {
-            LaunchScope ls(ctx, K_RADIX_SCATTER, 24.0 * count);
-            k_radix_chunked<<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(keys, vals, keys_alt, vals_alt, count, begin_bit + 8 * p,
-                                                                   p + 1 < npasses ? begin_bit + 8 * (p + 1) : -1, g, H + p * RS_NCH * 256,
-                                                                   H + (p + 1) * RS_NCH * 256, ctrl);
-        }
-        DK_HIP(ctx, hipGetLastError());
-        k_radix_fold_err<<<dim3(1), dim3(1), 0, st>>>(ctrl + 8, d_err);
-        std::swap(keys, keys_alt);
-        std::swap(vals, vals_alt);
-        ctx->stats.sort_passes += 1;
-        ctx->stats.sorted_elements += count;
-    }
-    ctx->ws_release(mark);
-    return DK_OK;
-}
-
+// text != nullptr: the pairs are (key of position i per TextKeys, i) for i < count = text->n; keys / vals need not hold anything on
+// entry (they are scratch), the first pass builds the keys from the text.
 int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
-               int begin_bit, int end_bit) {
-    if (count <= 1 || end_bit <= begin_bit) return DK_OK;
+               int begin_bit, int end_bit, const TextKeys *text) {
     if (count > 0xFFFFFFFEull) return ctx->fail(DK_E_ARG, "sort_pairs: count too large");
-    // default: three-phase passes with the XCD-aware tile order (measured 4.2 TB/s on the scatter); DK_SORT=onesweep selects the
-    // single-kernel look-back variant (no per-pass histogram, but ticket order defeats the XCD locality: 2.2 TB/s)
-    static const std::string mode = [] { const char *e = getenv("DK_SORT"); return std::string(e ? e : ""); }();
-    if (count < (1ull << 30)) {
-        if (mode == "onesweep") return sort_pairs_onesweep(ctx, keys, keys_alt, vals, vals_alt, count, begin_bit, end_bit);
-        if (mode == "chunked") return sort_pairs_chunked(ctx, keys, keys_alt, vals, vals_alt, count, begin_bit, end_bit);
-    }
-    return sort_pairs_classic(ctx, keys, keys_alt, vals, vals_alt, count, begin_bit, end_bit);
+    if (text && (count != text->n || end_bit <= begin_bit)) return ctx->fail(DK_E_INTERNAL, "sort_pairs: text pass needs at least one digit");
+    if (!text && (count <= 1 || end_bit <= begin_bit)) return DK_OK;
+    return sort_pairs_classic(ctx, keys, keys_alt, vals, vals_alt, count, begin_bit, end_bit, text);
 }
 
 // ---- bucketed scatter: dst[idx[i]] = val[i] for a huge, random idx ---------------------------------------------------
@@ -690,7 +415,7 @@ int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, 
     const size_t grid = 8 * div_up(ntiles, 8);
     {
         LaunchScope ls(ctx, K_RADIX_HIST, 8.0 * count);
-        k_radix_hist<true><<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(nullptr, idx, val, count, shift, tile_hist);
+        k_radix_hist<true><<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(nullptr, idx, val, count, shift, tile_hist, TextKeys{});
     }
     {
         LaunchScope ls(ctx, K_RADIX_SCAN, 3.0 * 1024.0 * ntiles);
@@ -700,8 +425,8 @@ int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, 
     }
     {
         LaunchScope ls(ctx, K_RADIX_SCATTER, 16.0 * count);
-        k_radix_scatter<false, true><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(nullptr, idx, val, scratch, nullptr, count, shift, tile_hist,
-                                                                              nullptr, nullptr, static_cast<uint32_t>(ntiles));
+        k_radix_scatter<true><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(nullptr, idx, val, scratch, nullptr, count, shift, tile_hist,
+                                                                       static_cast<uint32_t>(ntiles), TextKeys{});
     }
     {
         LaunchScope ls(ctx, K_BUCKET_STORE, 12.0 * count);
@@ -712,15 +437,6 @@ int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, 
     }
     DK_HIP(ctx, hipGetLastError());
     ctx->ws_release(mark);
-    return DK_OK;
-}
-
-// error word of the look-back path (non-zero: a spin hit its bound); resets it
-int sort_check_error(dk_ctx *ctx) {
-    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 12, ctx->d_mail + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    DK_HIP(ctx, hipMemsetAsync(ctx->d_mail + 12, 0, sizeof(uint32_t), ctx->stream));
-    DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->h_mail[12]) return ctx->fail(DK_E_INTERNAL, "radix sort: decoupled look-back timed out");
     return DK_OK;
 }
 
