@@ -12,8 +12,8 @@
 //                  number of run starts in the tile
 //   k_dc_runscan   exclusive sum of the run counts                     (run index of every tile's first new run)
 //   k_dc_carry_*   256-way "last non-empty" exclusive scan over tiles  (last occurrence before each tile, per symbol)
-//   k_dc_main      one wave per tile walks its runs in order; the 256-entry last-occurrence table lives in registers
-//                  (4 per lane), a rank is 4 compare+ballot+popcount, results go straight to the compact arrays
+//   k_dc_main      one wave per tile, 64 positions per step (lane = position); the 256-entry last-occurrence table lives in
+//                  wave-private LDS (s_pos / s_pr below), ranks are found lane-parallel, results go straight to the compact arrays
 //   k_dc_sweep     the final 256 distances
 // Algorithmic bytes: 3 n (three reads of L) + 6 m (dist, sym, rank per run) + 2 * 2 KiB per tile of tables.
 #include "context.hpp"
@@ -291,12 +291,25 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
             const uint32_t pw = static_cast<uint32_t>(__shfl(static_cast<int>(incl - pc), word, 64));
             const uint32_t below = pw + static_cast<uint32_t>(__popcll(mw & ((1ull << (lo & 63u)) - 1ull)));
             uint32_t rk = total - below;
-            uint64_t fm = __ballot(first_here);
-            while (fm) {
-                const int bit = __builtin_ctzll(fm);
-                fm &= fm - 1;
-                const uint32_t tq = __builtin_amdgcn_readlane(tab.x, bit);
-                rk += (bit < lane && tq <= b1) ? 1u : 0u;
+            // + the symbols first seen in this chunk in an EARLIER lane whose own previous occurrence is not after mine (their mark sits
+            // at or before b, so the bitmap did not count them).  A dominance count over at most 64 lanes: previous occurrences before
+            // the tile (or none) always qualify -- one ballot; among the in-tile ones the previous positions are distinct 12-bit
+            // numbers, compared bit-sliced from the top: E = the earlier lanes that still agree with me on the bits seen so far; where
+            // my bit is 1, those of them with a 0 are smaller.  12 x (ballot, and, popcount) instead of a scalar loop over ~57 lanes.
+            {
+                const uint64_t outside = __ballot(first_here && !in_tile);
+                const bool memb = first_here && in_tile;
+                const uint32_t K = memb ? (b1 - 1u - base32) : 0u;  // position of my previous occurrence inside the tile
+                uint64_t E = __ballot(memb) & lt;
+                uint32_t dom = static_cast<uint32_t>(__popcll(outside & lt));
+#pragma unroll
+                for (int k = 11; k >= 0; --k) {
+                    const bool bit = (K >> k) & 1u;
+                    const uint64_t B = __ballot(bit);
+                    dom += bit ? static_cast<uint32_t>(__popcll(E & ~B)) : 0u;
+                    E &= bit ? B : ~B;
+                }
+                rk += dom;
             }
             if (isB) cnt = in_tile ? rk : 0u;
             uint64_t slow = __ballot(isB && b1 != 0 && !in_tile);

@@ -318,6 +318,95 @@ __global__ __launch_bounds__(RS_BLOCK) void k_radix_scatter(const uint64_t *__re
     }
 }
 
+// ---- small inputs: the whole sort in ONE workgroup --------------------------------------------------------------------------------
+// The big-group lists of the later suffix-sort rounds hold a few thousand pairs: five launches per digit (histogram, three scans,
+// scatter) would be nothing but launch latency.  Up to SS_MAX pairs are sorted by one workgroup of 1024 threads, all passes inside
+// the kernel: per pass every wave ranks its pairs with the same ballots as k_radix_scatter, the pairs are reordered through LDS, and
+// stay in registers (position-striped) between passes.
+constexpr int SS_BLOCK = 1024;
+constexpr int SS_WAVES = SS_BLOCK / 64;
+constexpr int SS_KPT = 8;
+constexpr int SS_MAX = SS_BLOCK * SS_KPT;  // 8192 pairs
+
+__global__ __launch_bounds__(SS_BLOCK) void k_radix_sort_small(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t count,
+                                                               int begin_bit, int end_bit) {
+    __shared__ uint64_t s_keys[SS_MAX];
+    __shared__ uint32_t s_vals[SS_MAX];
+    __shared__ uint32_t s_cnt[SS_WAVES][256];
+    __shared__ uint32_t s_start[256];
+    __shared__ uint32_t s_tmp[SS_WAVES + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t lt = lanemask_lt(lane);
+    // wave w owns positions [w * 512, (w + 1) * 512), lane-striped: position order = (wave, k, lane)
+    const uint32_t wbase = static_cast<uint32_t>(wave) * (64 * SS_KPT);
+    uint64_t key[SS_KPT];
+    uint32_t val[SS_KPT];
+#pragma unroll
+    for (int k = 0; k < SS_KPT; ++k) {
+        const uint32_t li = wbase + k * 64 + lane;
+        key[k] = li < count ? keys[li] : ~0ull;  // padding: sorts last in every pass (all-ones digits), stays behind the real pairs (stable)
+        val[k] = li < count ? vals[li] : 0u;
+    }
+    for (int shift = begin_bit; shift < end_bit; shift += 8) {
+        for (int i = tid; i < SS_WAVES * 256; i += SS_BLOCK) (&s_cnt[0][0])[i] = 0;
+        __syncthreads();
+        uint32_t rnk[SS_KPT];
+#pragma unroll
+        for (int k = 0; k < SS_KPT; ++k) {
+            const uint32_t d = digit_of(key[k], shift);
+            uint64_t same = ~0ull;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                same &= bit ? bal : ~bal;
+            }
+            const uint32_t before = static_cast<uint32_t>(__popcll(same & lt));
+            const uint32_t old = s_cnt[wave][d];
+            __builtin_amdgcn_wave_barrier();
+            if (before == 0) s_cnt[wave][d] = old + static_cast<uint32_t>(__popcll(same));
+            __builtin_amdgcn_wave_barrier();
+            rnk[k] = old + before;
+        }
+        __syncthreads();
+        {
+            const int d = tid & 255;
+            uint32_t run = 0;
+            if (tid < 256) {
+#pragma unroll
+                for (int w = 0; w < SS_WAVES; ++w) {
+                    const uint32_t c = s_cnt[w][d];
+                    s_cnt[w][d] = run;
+                    run += c;
+                }
+            }
+            const uint32_t start = block_excl_sum<SS_WAVES>(run, s_tmp, nullptr);
+            if (tid < 256) s_start[d] = start;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SS_KPT; ++k) {
+            const uint32_t d = digit_of(key[k], shift);
+            const uint32_t p = s_start[d] + s_cnt[wave][d] + rnk[k];
+            s_keys[p] = key[k];
+            s_vals[p] = val[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SS_KPT; ++k) {
+            const uint32_t li = wbase + k * 64 + lane;
+            key[k] = s_keys[li];
+            val[k] = s_vals[li];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < SS_KPT; ++k) {
+        const uint32_t li = wbase + k * 64 + lane;
+        if (li < count) { keys[li] = key[k]; vals[li] = val[k]; }
+    }
+}
+
 }  // namespace
 
 // Sorts `count` pairs on key bits [begin_bit, end_bit).  keys/vals are the input buffers, *_alt equally sized scratch;
@@ -374,6 +463,17 @@ int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&val
     if (count > 0xFFFFFFFEull) return ctx->fail(DK_E_ARG, "sort_pairs: count too large");
     if (text && (count != text->n || end_bit <= begin_bit)) return ctx->fail(DK_E_INTERNAL, "sort_pairs: text pass needs at least one digit");
     if (!text && (count <= 1 || end_bit <= begin_bit)) return DK_OK;
+    if (!text && count <= static_cast<size_t>(SS_MAX)) {  // in place, one launch
+        const int npasses = (end_bit - begin_bit + 7) / 8;
+        {
+            LaunchScope ls(ctx, K_RADIX_SCATTER, 24.0 * count);
+            k_radix_sort_small<<<dim3(1), dim3(SS_BLOCK), 0, ctx->stream>>>(keys, vals, static_cast<uint32_t>(count), begin_bit, end_bit);
+        }
+        DK_HIP(ctx, hipGetLastError());
+        ctx->stats.sort_passes += static_cast<uint32_t>(npasses);
+        ctx->stats.sorted_elements += count * static_cast<size_t>(npasses);
+        return DK_OK;
+    }
     return sort_pairs_classic(ctx, keys, keys_alt, vals, vals_alt, count, begin_bit, end_bit, text);
 }
 

@@ -710,9 +710,12 @@ __global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__res
                                                            uint32_t *__restrict__ idx_out, uint32_t *__restrict__ meta_out,
                                                            uint8_t *__restrict__ sym_out, uint32_t *__restrict__ sa,
                                                            uint8_t *__restrict__ bwt, uint32_t *__restrict__ origin,
-                                                           uint32_t *__restrict__ live) {
+                                                           uint32_t *__restrict__ live, const uint32_t *__restrict__ prev_live) {
     __shared__ uint32_t s_r2[LS_TILE + 2 * LS_MAX];
     __shared__ uint32_t s_cnt[RR_WAVES];
+    // launched one round ahead of the host: when the round before left nothing alive there is nothing to do (and nothing to copy:
+    // nobody reads the lists again)
+    if (prev_live && *prev_live == 0) return;
     const int tid = threadIdx.x;
     const size_t b0 = static_cast<size_t>(blockIdx.x) * LS_TILE;
     uint32_t my_idx[LS_IPT], my_r2[LS_IPT];
@@ -775,7 +778,9 @@ __global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__res
 
 // the rank updates of the round k_plateau_sort just ran: members of a group with a new head get that head's SA position
 __global__ __launch_bounds__(256) void k_plateau_ranks(const uint32_t *__restrict__ idx, const uint32_t *__restrict__ meta,
-                                                        const uint32_t *__restrict__ pos, size_t slots, uint32_t *__restrict__ rank) {
+                                                        const uint32_t *__restrict__ pos, size_t slots, uint32_t *__restrict__ rank,
+                                                        const uint32_t *__restrict__ prev_live) {
+    if (prev_live && *prev_live == 0) return;  // the sort kernel of this round did nothing
     const size_t a = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (a >= slots) return;
     const uint32_t v = idx[a];
@@ -1137,11 +1142,13 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
             {
                 LaunchScope ls(ctx, K_PLATEAU_SORT, 6.0 * slots + 4.0 * live + 10.0 * live);
                 k_plateau_sort<<<dim3(div_up(slots, LS_TILE)), dim3(LS_BLOCK), 0, st>>>(idx_a, meta_a, sym_a, pos, rank, static_cast<uint32_t>(n), h_eff,
-                                                                                      slots, idx_b, meta_b, sym_b, d_sa, d_bwt, d_origin, cnt);
+                                                                                      slots, idx_b, meta_b, sym_b, d_sa, d_bwt, d_origin, cnt,
+                                                                                      launched ? d_live + ((launched - 1) & 7u) : nullptr);
             }
             {
                 LaunchScope ls(ctx, K_PLATEAU_RANKS, 6.0 * slots);
-                k_plateau_ranks<<<dim3(div_up(slots, 256)), dim3(256), 0, st>>>(idx_b, meta_b, pos, slots, rank);
+                k_plateau_ranks<<<dim3(div_up(slots, 256)), dim3(256), 0, st>>>(idx_b, meta_b, pos, slots, rank,
+                                                                                launched ? d_live + ((launched - 1) & 7u) : nullptr);
             }
             DK_HIP(ctx, hipGetLastError());
             DK_HIP(ctx, hipMemcpyAsync(h_live + (launched & 7u), cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
