@@ -461,7 +461,33 @@ def main():
             "datagen_s": round(t_gen, 2),
         }
         if dstats:
-            result["decode_stage_ms"] = {kk: round(dstats[kk], 3) for kk in ("ms_entropy", "ms_h2d", "ms_ibwt", "ms_total")}
+            result["decode_stage_ms"] = {kk: round(dstats[kk], 3) for kk in ("ms_entropy", "ms_h2d", "ms_ibwt", "ms_total")}  # last step
+            # where the host half of the decode goes, nanoseconds per distance, each part timed alone on this block (rank 0): the range
+            # decoder + model fed the symbol sequence (dk_model_decode), and the rebuild of L from the distances (dk_dc_decode)
+            try:
+                from dark_amd import model as _model
+                d_bwt = torch.empty(n, dtype=torch.uint8, device=dev)
+                ctx.dev_bwt_forward(d_in, n, d_bwt)
+                d_dist = torch.empty(n, dtype=torch.int32, device=dev)
+                d_sym = torch.empty(n, dtype=torch.uint8, device=dev)
+                init, m_runs = ctx.dev_dc_encode(d_bwt, n, d_dist, d_sym)
+                dist_h = d_dist[:m_runs].cpu().numpy().view(np.uint32)
+                sym_h = d_sym[:m_runs].cpu().numpy()
+                del d_bwt, d_dist, d_sym
+                coded = _model.encode(args.model, dist_h, sym_h)
+                t_a = time.perf_counter()
+                back = _model.decode(args.model, coded, sym_h)
+                t_a = time.perf_counter() - t_a
+                t_b = time.perf_counter()
+                ctx.dc_decode(init, dist_h, n)
+                t_b = time.perf_counter() - t_b
+                result["decode_ns_per_distance"] = {"distances": int(m_runs),
+                                                    "whole_host_stage": round(1e6 * result["decode_stage_ms"]["ms_entropy"] / m_runs, 2),
+                                                    "range_decoder_and_model_alone": round(1e9 * t_a / m_runs, 2),
+                                                    "dc_rebuild_alone": round(1e9 * t_b / m_runs, 2),
+                                                    "model_roundtrip_ok": bool((back == dist_h).all())}
+            except dark_amd.DarkError as e:
+                result["decode_ns_per_distance"] = {"error": str(e)}
             result["decode_kernel_ms_per_step"] = {kk: round(v["ms"] / k, 3) for kk, v in sorted(dstats["kernels"].items(), key=lambda x: -x[1]["ms"])}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import orc  # the checker, timed as the CPU baseline (never the thing measured above)

@@ -72,13 +72,41 @@ __device__ __forceinline__ void text_tile_keys(const TextKeys &tk, size_t b0, ui
     const int base = tid * RS_KPT;  // RS_KPT consecutive positions per thread: a sliding window over the codes
     const int bits = tk.bits, spk = tk.spk;
     const uint64_t mask = (spk * bits >= 64) ? ~0ull : ((1ull << (spk * bits)) - 1ull);
+    // 16 staged codes from byte offset `off` on (any alignment), as two little-endian words: three aligned 8-byte LDS reads
+    auto bytes16 = [&](int off, uint64_t &lo, uint64_t &hi) {
+        const uint64_t *q = reinterpret_cast<const uint64_t *>(s_c + (off & ~7));
+        const unsigned sh = static_cast<unsigned>(off & 7) * 8u;
+        const uint64_t a = q[0], b = q[1], c = q[2];
+        lo = sh ? (a >> sh) | (b << (64u - sh)) : a;
+        hi = sh ? (b >> sh) | (c << (64u - sh)) : b;
+    };
     uint64_t key = 0;
-    for (int j = 0; j < spk; ++j) key = (key << bits) | s_c[base + j];
+    for (int j0 = 0; j0 < spk; j0 += 16) {  // first key of the thread: the codes of positions base .. base + spk - 1
+        uint64_t lo, hi;
+        bytes16(base + j0, lo, hi);
+        const int cnt = spk - j0 < 16 ? spk - j0 : 16;
+        for (int j = 0; j < cnt; ++j) {
+            const uint64_t w = j < 8 ? lo : hi;
+            key = (key << bits) | ((w >> (8 * (j & 7))) & 0xFFu);
+        }
+    }
+    uint64_t nlo, nhi, plo = 0, phi = 0;
+    bytes16(base + spk, nlo, nhi);  // the codes that enter the window: positions base + spk .. base + spk + 15
+    uint32_t before = s_c[RS_TILE + RS_TEXT_AHEAD];
+    if (tk.with_prev) {  // codes of positions base - 1 .. base + 14
+        if (base) { bytes16(base - 1, plo, phi); } else { bytes16(0, plo, phi); phi = (phi << 8) | (plo >> 56); plo = (plo << 8) | before; }
+    }
 #pragma unroll
     for (int g = 0; g < RS_KPT; ++g) {
-        if (g) key = ((key << bits) | s_c[base + spk + g - 1]) & mask;
+        if (g) {
+            const uint64_t w = g - 1 < 8 ? nlo : nhi;
+            key = ((key << bits) | ((w >> (8 * ((g - 1) & 7))) & 0xFFu)) & mask;
+        }
         uint64_t out = key;
-        if (tk.with_prev) out = (key << 8) | (base + g ? s_c[base + g - 1] : s_c[RS_TILE + RS_TEXT_AHEAD]);
+        if (tk.with_prev) {
+            const uint64_t w = g < 8 ? plo : phi;
+            out = (key << 8) | ((w >> (8 * (g & 7))) & 0xFFu);
+        }
         sink(base + g, out);
     }
 }
