@@ -43,6 +43,7 @@ enum KernelSlot : int {
     K_PLACE_ACTIVE,    // k_place_active + k_rank_active
     K_PLATEAU_SORT,
     K_PLATEAU_RANKS,   // k_plateau_ranks, k_to_inplace, k_plateau_count/_scan/_compact
+    K_RADIX_SORT_SMALL,
     K_SLOT_COUNT
 };
 static_assert(K_SLOT_COUNT <= DK_NUM_KERNEL_SLOTS, "grow DK_NUM_KERNEL_SLOTS");

@@ -494,7 +494,7 @@ int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&val
     if (!text && count <= static_cast<size_t>(SS_MAX)) {  // in place, one launch
         const int npasses = (end_bit - begin_bit + 7) / 8;
         {
-            LaunchScope ls(ctx, K_RADIX_SCATTER, 24.0 * count);
+            LaunchScope ls(ctx, K_RADIX_SORT_SMALL, 24.0 * count);
             k_radix_sort_small<<<dim3(1), dim3(SS_BLOCK), 0, ctx->stream>>>(keys, vals, static_cast<uint32_t>(count), begin_bit, end_bit);
         }
         DK_HIP(ctx, hipGetLastError());
