@@ -308,38 +308,22 @@ constexpr BwtCarry NO_CARRY{0, nullptr, nullptr, nullptr, nullptr, nullptr};
 // pos_in == nullptr means slot a sits at SA position a (first rerank, straight after the initial sort).
 // All tile inputs arrive through LDS with lane-contiguous loads; the compacted outputs leave through LDS the same way.
 // FIRST = (pos_in == nullptr): no position array to stage, 8 KiB of LDS less -> more workgroups per CU for the largest launch
-// FUSED: one kernel instead of reduce / scan / apply.  Tiles are handed out by an atomic ticket (a tile only ever waits for tiles
-// that already started); every tile publishes its aggregate (survivors, surviving heads | last head) as two self-flagged 64-bit words
-// and finds its exclusive prefix by decoupled look-back over the preceding tiles' words (relaxed agent-scope atomics: the word IS
-// the flag, so no fence is needed).  Every spin is bounded and sets an error word.
-struct FusedCtl { unsigned long long *status; uint32_t *ticket; uint32_t *err; uint32_t *mail; uint32_t ntiles; };
-constexpr unsigned long long RS_AGG = 1ull << 62, RS_PREFIX = 2ull << 62;
-constexpr uint32_t RR_SPIN_LIMIT = 1u << 24;
-
-template <bool FIRST, bool FUSED>
+template <bool FIRST>
 __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx,
                                                             const uint32_t *__restrict__ pos_in, size_t count, const uint32_t *__restrict__ gid_in,
                                                             const RerankAgg *__restrict__ agg, uint32_t *__restrict__ rank,
                                                             uint32_t *__restrict__ sa, uint32_t *__restrict__ out_idx,
                                                             uint32_t *__restrict__ out_pos, uint32_t *__restrict__ out_gid,
                                                             uint32_t *__restrict__ gstart, uint32_t *__restrict__ headpos_out,
-                                                            BwtCarry bc, FusedCtl fc) {
+                                                            BwtCarry bc) {
     __shared__ uint64_t s_key[RR_TILE + 2];                       // later reused: compacted idx | pos
     __shared__ __attribute__((aligned(16))) uint32_t s_idx[RR_TILE];
     __shared__ __attribute__((aligned(16))) uint32_t s_pos[FIRST ? 4 : RR_TILE];
     __shared__ __attribute__((aligned(8))) uint8_t s_flag[RR_TILE];
     __shared__ __attribute__((aligned(8))) uint8_t s_low[RR_TILE];  // bc.bwt: FIRST: previous-symbol codes of the tile; later: compacted symbols
     __shared__ uint32_t s_tmp[RR_WAVES + 1];
-    __shared__ uint32_t s_tile;
-    __shared__ RerankAgg s_base;
     const int tid = threadIdx.x;
-    uint32_t tile = blockIdx.x;
-    if (FUSED) {
-        if (tid == 0) s_tile = atomicAdd(fc.ticket, 1u);
-        __syncthreads();
-        tile = s_tile;
-    }
-    const size_t b0 = static_cast<size_t>(tile) * RR_TILE;
+    const size_t b0 = static_cast<size_t>(blockIdx.x) * RR_TILE;
 #pragma unroll
     for (int k = 0; k < RR_IPT; ++k) {
         const int o = k * RR_BLOCK + tid;
@@ -378,59 +362,11 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
     }
     uint32_t ns, nh, lh;
     thread_summary(fl, a0, ns, nh, lh);
-    uint32_t block_surv, block_heads, block_last;
+    const RerankAgg base = agg[blockIdx.x];
+    uint32_t block_surv;
     uint32_t es = block_excl_sum<RR_WAVES>(ns, s_tmp, &block_surv);  // tile-local compaction offset
-    uint32_t eh = block_excl_sum<RR_WAVES>(nh, s_tmp, &block_heads);
-    uint32_t el = block_excl_max<RR_WAVES>(lh, s_tmp, &block_last);
-    if (FUSED) {
-        if (tid == 0) {
-            unsigned long long *mine = fc.status + 2 * static_cast<size_t>(tile);
-            const unsigned long long agg0 = (static_cast<unsigned long long>(block_surv) << 31) | block_heads;
-            uint32_t bs = 0, bh = 0, bl = 0;
-            if (tile == 0) {
-                __hip_atomic_store(mine + 1, RS_PREFIX | block_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(mine, RS_PREFIX | agg0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                __hip_atomic_store(mine + 1, RS_AGG | block_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(mine, RS_AGG | agg0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                uint32_t spins = 0;
-                for (size_t p = tile; p-- > 0;) {
-                    unsigned long long w0, w1;
-                    for (;;) {  // predecessor's counts
-                        w0 = __hip_atomic_load(fc.status + 2 * p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (w0 >> 62) break;
-                        if (++spins > RR_SPIN_LIMIT) { *fc.err = 1; break; }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    const bool prefix = (w0 >> 62) == 2;
-                    for (;;) {  // its last head: the inclusive form when the counts were inclusive
-                        w1 = __hip_atomic_load(fc.status + 2 * p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((w1 >> 62) == (prefix ? 2u : 1u) || (!prefix && (w1 >> 62) == 2)) break;
-                        if (++spins > RR_SPIN_LIMIT) { *fc.err = 1; break; }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    bs += static_cast<uint32_t>((w0 >> 31) & 0x7FFFFFFFu);
-                    bh += static_cast<uint32_t>(w0 & 0x7FFFFFFFu);
-                    const uint32_t l = static_cast<uint32_t>(w1);
-                    bl = bl > l ? bl : l;
-                    if (prefix || spins > RR_SPIN_LIMIT) break;
-                }
-                const uint32_t il = bl > block_last ? bl : block_last;
-                __hip_atomic_store(mine + 1, RS_PREFIX | il, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(mine, RS_PREFIX | (static_cast<unsigned long long>(bs + block_surv) << 31) | (bh + block_heads),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            s_base = RerankAgg{bs, bh, bl, 0};
-            if (tile == fc.ntiles - 1) {  // totals and the sentinel "one past the last group"
-                fc.mail[0] = bs + block_surv;
-                fc.mail[1] = bh + block_heads;
-                gstart[bh + block_heads] = bs + block_surv;
-            }
-        }
-        __syncthreads();
-    }
-    const RerankAgg base = FUSED ? s_base : agg[tile];
-    eh += base.heads;
+    uint32_t eh = base.heads + block_excl_sum<RR_WAVES>(nh, s_tmp, nullptr);
+    uint32_t el = block_excl_max<RR_WAVES>(lh, s_tmp, nullptr);
     el = el > base.last_head ? el : base.last_head;
     uint32_t *s_oidx = reinterpret_cast<uint32_t *>(s_key);
     uint32_t *s_opos = s_oidx + RR_TILE;
@@ -495,30 +431,9 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
            bool probe_active = false, bool *ranks_written = nullptr, BwtCarry fb = NO_CARRY) {
     const size_t ntiles = div_up(count, RR_TILE);
     const size_t mark = ctx->ws_mark();
-    hipStream_t st = ctx->stream;
-    if (ranks_written) *ranks_written = true;
-    // DK_RERANK=classic (A/B and test hook): the three-kernel form for every call (probe_active needs it anyway: the host reads the
-    // survivor count between the scan and the apply phase)
-    static const bool classic_env = [] { const char *e = getenv("DK_RERANK"); return e && e[0] == 'c'; }();
-    if (!probe_active && !classic_env) {
-        unsigned long long *status = ctx->ws_alloc<unsigned long long>(2 * ntiles + 2);
-        if (!status) return DK_E_NOMEM;
-        uint32_t *ctl = reinterpret_cast<uint32_t *>(status + 2 * ntiles);  // ticket, error word: cleared with the status words
-        DK_HIP(ctx, hipMemsetAsync(status, 0, (2 * ntiles + 2) * sizeof(unsigned long long), st));
-        const FusedCtl fc{status, ctl, ctx->d_mail + 12, ctx->d_mail, static_cast<uint32_t>(ntiles)};
-        {
-            LaunchScope ls(ctx, K_RERANK_APPLY, 8.0 * count + 4.0 * count + 4.0 * count + 12.0 * count);
-            if (pos_in)
-                k_rerank_apply<false, true><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gid_in, nullptr, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out, fb, fc);
-            else
-                k_rerank_apply<true, true><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gid_in, nullptr, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out, fb, fc);
-        }
-        DK_HIP(ctx, hipGetLastError());
-        ctx->ws_release(mark);
-        return DK_OK;
-    }
     RerankAgg *agg = ctx->ws_alloc<RerankAgg>(ntiles);
     if (!agg) return DK_E_NOMEM;
+    hipStream_t st = ctx->stream;
     {
         LaunchScope ls(ctx, K_RERANK_REDUCE, 8.0 * count);
         k_rerank_reduce<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, count, gid_in, agg, pos_in ? 0 : fb.cmp_shift);
@@ -527,6 +442,7 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
         LaunchScope ls(ctx, K_RERANK_SCAN, 32.0 * ntiles);
         k_rerank_scan<<<dim3(1), dim3(1024), 0, st>>>(agg, ntiles, ctx->d_mail, gstart);
     }
+    if (ranks_written) *ranks_written = true;
     if (probe_active) {
         DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         DK_HIP(ctx, hipStreamSynchronize(st));
@@ -536,13 +452,12 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
             if (ranks_written) *ranks_written = false;
         }
     }
-    const FusedCtl none{nullptr, nullptr, nullptr, nullptr, 0};
     {
         LaunchScope ls(ctx, K_RERANK_APPLY, 8.0 * count + 4.0 * count + 4.0 * count + 12.0 * count);
         if (pos_in)
-            k_rerank_apply<false, false><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gid_in, agg, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out, fb, none);
+            k_rerank_apply<false><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gid_in, agg, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out, fb);
         else
-            k_rerank_apply<true, false><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gid_in, agg, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out, fb, none);
+            k_rerank_apply<true><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gid_in, agg, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out, fb);
     }
     DK_HIP(ctx, hipGetLastError());
     ctx->ws_release(mark);
@@ -1291,11 +1206,6 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     }
     if (carry_bwt) *bwt_written = true;
     ctx->ws_release(mark);
-    // error word of the fused rerank's look-back (a spin that hit its bound); cleared for the next call
-    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 12, ctx->d_mail + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    DK_HIP(ctx, hipMemsetAsync(ctx->d_mail + 12, 0, sizeof(uint32_t), st));
-    DK_HIP(ctx, hipStreamSynchronize(st));
-    if (ctx->h_mail[12]) return ctx->fail(DK_E_INTERNAL, "suffix_array: rerank look-back timed out");
     return DK_OK;
 }
 
