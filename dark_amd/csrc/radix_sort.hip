@@ -199,6 +199,22 @@ __global__ __launch_bounds__(1024) void k_radix_scan_b(uint32_t *__restrict__ ch
 #pragma unroll 8
     for (size_t g = g0; g < g1; ++g) chunk_sum[g * 256 + d] += off;
 }
+// all three phases in one workgroup, for sorts of few tiles (the big-group lists: a launch costs more than this loop)
+__global__ __launch_bounds__(256) void k_radix_scan_small(uint32_t *__restrict__ tile_hist, size_t ntiles) {
+    __shared__ uint32_t s_tmp[4 + 1];
+    const int d = threadIdx.x;
+    uint32_t run = 0;
+#pragma unroll 8
+    for (size_t t = 0; t < ntiles; ++t) {
+        const uint32_t v = tile_hist[t * 256 + d];
+        tile_hist[t * 256 + d] = run;
+        run += v;
+    }
+    const uint32_t base = block_excl_sum<4>(run, s_tmp, nullptr);
+#pragma unroll 8
+    for (size_t t = 0; t < ntiles; ++t) tile_hist[t * 256 + d] += base;
+}
+
 // phase C: tile counts -> exclusive global offsets
 __global__ __launch_bounds__(256) void k_radix_scan_c(uint32_t *__restrict__ tile_hist, size_t ntiles, size_t tiles_per_chunk,
                                                        const uint32_t *__restrict__ chunk_sum) {
@@ -459,9 +475,13 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
         }
         {
             LaunchScope ls(ctx, K_RADIX_SCAN, 3.0 * 1024.0 * ntiles);
-            k_radix_scan_a<<<dim3(nchunks), dim3(256), 0, st>>>(tile_hist, ntiles, tiles_per_chunk, chunk_sum);
-            k_radix_scan_b<<<dim3(1), dim3(1024), 0, st>>>(chunk_sum, nchunks);
-            k_radix_scan_c<<<dim3(nchunks), dim3(256), 0, st>>>(tile_hist, ntiles, tiles_per_chunk, chunk_sum);
+            if (ntiles <= 1024) {
+                k_radix_scan_small<<<dim3(1), dim3(256), 0, st>>>(tile_hist, ntiles);
+            } else {
+                k_radix_scan_a<<<dim3(nchunks), dim3(256), 0, st>>>(tile_hist, ntiles, tiles_per_chunk, chunk_sum);
+                k_radix_scan_b<<<dim3(1), dim3(1024), 0, st>>>(chunk_sum, nchunks);
+                k_radix_scan_c<<<dim3(nchunks), dim3(256), 0, st>>>(tile_hist, ntiles, tiles_per_chunk, chunk_sum);
+            }
         }
         {
             LaunchScope ls(ctx, K_RADIX_SCATTER, (text && shift == begin_bit ? 13.0 : 24.0) * count);

@@ -466,8 +466,10 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
 
 // ---- big / small classification of the groups of the next round ---------------------------------------------------
 // A group of more than LS_MAX members goes through the global radix sort; bigstart[g] = number of slots in big groups
-// before group g (exclusive scan of the big sizes), bigstart[groups] = total -> mail[2].
-constexpr int LS_MAX = 256;
+// before group g (exclusive scan of the big sizes), bigstart[groups] = total -> mail[2].  mail[3] = number of slots in groups of more
+// than PL_MAX members (those keep the sort in general rounds; zero = the in-place rounds can take over).
+constexpr int LS_MAX = 1024;  // general rounds: groups up to this size are sorted inside a workgroup's LDS
+constexpr int PL_MAX = 256;   // in-place (plateau) rounds need every group to have at most this many members (9-bit offsets)
 constexpr int BG_IPT = 16;
 constexpr int BG_TILE = 256 * BG_IPT;
 
@@ -482,13 +484,21 @@ __global__ __launch_bounds__(256) void k_big_reduce(const uint32_t *__restrict__
     __shared__ uint32_t s_w[RR_WAVES];
     const size_t groups = mail[1];
     const size_t g0 = static_cast<size_t>(blockIdx.x) * BG_TILE + static_cast<size_t>(threadIdx.x) * BG_IPT;
-    uint32_t sum = 0;
+    uint32_t sum = 0, medium = 0;
     if (g0 < groups) {
 #pragma unroll
-        for (int j = 0; j < BG_IPT; ++j) sum += big_size(gstart, g0 + j, groups);
+        for (int j = 0; j < BG_IPT; ++j) {
+            sum += big_size(gstart, g0 + j, groups);
+            if (g0 + j < groups) {
+                const uint32_t sz = gstart[g0 + j + 1] - gstart[g0 + j];
+                medium += sz > static_cast<uint32_t>(PL_MAX) ? sz : 0u;
+            }
+        }
     }
     sum = wave_sum(sum);
+    medium = wave_sum(medium);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
+    if ((threadIdx.x & 63) == 0 && medium) atomicAdd(const_cast<uint32_t *>(mail) + 3, medium);
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
@@ -627,13 +637,19 @@ __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__rest
             s_r2[LS_MAX + k * LS_BLOCK + tid] = my_r2[k];
         }
     }
-    for (int t = tid; t < 2 * LS_MAX; t += LS_BLOCK) {  // halo: LS_MAX slots before the tile, LS_MAX after
-        const bool left = t < LS_MAX;
-        const size_t off = left ? static_cast<size_t>(t) : static_cast<size_t>(LS_TILE) + LS_MAX + (t - LS_MAX);
-        // slot index = b0 - LS_MAX + off; guard both ends of the list
-        if (b0 + off >= static_cast<size_t>(LS_MAX) && b0 + off - LS_MAX < count) {
-            const size_t a = b0 + off - LS_MAX;
-            s_r2[off] = second(act_idx[a]);
+    // halo: up to LS_MAX slots before the tile and after it -- but only those that belong to the group of the tile's first / last slot
+    // (nothing else in the halo is ever looked at), so a halo slot costs its gather only when a group really straddles the tile edge
+    {
+        const size_t last = (b0 + LS_TILE <= count ? b0 + LS_TILE : count) - 1;
+        const uint32_t g_first = act_gid[b0], g_last = act_gid[last];
+        for (int t = tid; t < 2 * LS_MAX; t += LS_BLOCK) {
+            const bool left = t < LS_MAX;
+            const size_t off = left ? static_cast<size_t>(t) : static_cast<size_t>(LS_TILE) + LS_MAX + (t - LS_MAX);
+            // slot index = b0 - LS_MAX + off; guard both ends of the list
+            if (b0 + off >= static_cast<size_t>(LS_MAX) && b0 + off - LS_MAX < count) {
+                const size_t a = b0 + off - LS_MAX;
+                if (act_gid[a] == (left ? g_first : g_last)) s_r2[off] = second(act_idx[a]);
+            }
         }
     }
     __syncthreads();
@@ -681,7 +697,7 @@ __global__ __launch_bounds__(256) void k_big_back(const uint64_t *__restrict__ b
     if (sym_out) sym_out[a] = text[suffix ? suffix - 1 : n - 1];
 }
 
-// ---- plateau rounds: every group has at most LS_MAX members ---------------------------------------------------------------------
+// ---- plateau rounds: every group has at most PL_MAX members ---------------------------------------------------------------------
 // Once a round ends without a big group there will never be one again (groups only split), and what is left are typically the
 // suffixes inside long repeats: the list shrinks slowly for log2(repeat length) rounds.  These rounds run on an IN-PLACE list:
 //   idx[a]   suffix in slot a; bit 31 set = the slot is dead (its suffix is final)
@@ -711,7 +727,7 @@ __global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__res
                                                            uint8_t *__restrict__ sym_out, uint32_t *__restrict__ sa,
                                                            uint8_t *__restrict__ bwt, uint32_t *__restrict__ origin,
                                                            uint32_t *__restrict__ live, const uint32_t *__restrict__ prev_live) {
-    __shared__ uint32_t s_r2[LS_TILE + 2 * LS_MAX];
+    __shared__ uint32_t s_r2[LS_TILE + 2 * PL_MAX];
     __shared__ uint32_t s_cnt[RR_WAVES];
     // launched one round ahead of the host: when the round before left nothing alive there is nothing to do (and nothing to copy:
     // nobody reads the lists again)
@@ -724,14 +740,24 @@ __global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__res
         const size_t a = b0 + static_cast<size_t>(k) * LS_BLOCK + tid;
         my_idx[k] = a < slots ? idx_in[a] : PL_DEAD;
         my_r2[k] = (my_idx[k] & PL_DEAD_BIT) ? 0u : rank2_of(rank, my_idx[k], n, h);
-        s_r2[LS_MAX + k * LS_BLOCK + tid] = my_r2[k];
+        s_r2[PL_MAX + k * LS_BLOCK + tid] = my_r2[k];
     }
-    for (int t = tid; t < 2 * LS_MAX; t += LS_BLOCK) {  // halo: LS_MAX slots before the tile, LS_MAX after
-        const bool left = t < LS_MAX;
-        const size_t off = left ? static_cast<size_t>(t) : static_cast<size_t>(LS_TILE) + LS_MAX + (t - LS_MAX);
-        if (b0 + off >= static_cast<size_t>(LS_MAX) && b0 + off - LS_MAX < slots) {
-            const uint32_t v = idx_in[b0 + off - LS_MAX];
-            s_r2[off] = (v & PL_DEAD_BIT) ? 0u : rank2_of(rank, v, n, h);
+    // halo: only the slots of the groups that straddle the tile's edges (the group of the tile's first live slot reaches back by its
+    // offset, the group of its last live slot forward by size - 1 - offset); nothing else in the halo is ever looked at
+    {
+        const size_t last = (b0 + LS_TILE <= slots ? b0 + LS_TILE : slots) - 1;
+        const uint32_t m_first = (idx_in[b0] & PL_DEAD_BIT) ? 0u : meta_in[b0];
+        const uint32_t m_last = (idx_in[last] & PL_DEAD_BIT) ? 0u : meta_in[last];
+        const uint32_t need_left = m_first & PL_OFF_MASK;
+        const uint32_t need_right = (idx_in[last] & PL_DEAD_BIT) ? 0u : ((m_last >> 9) & PL_OFF_MASK) - (m_last & PL_OFF_MASK);
+        for (int t = tid; t < 2 * PL_MAX; t += LS_BLOCK) {
+            const bool left = t < PL_MAX;
+            const size_t off = left ? static_cast<size_t>(t) : static_cast<size_t>(LS_TILE) + PL_MAX + (t - PL_MAX);
+            const bool wanted = left ? static_cast<uint32_t>(PL_MAX - t) <= need_left : static_cast<uint32_t>(t - PL_MAX) < need_right;
+            if (wanted && b0 + off >= static_cast<size_t>(PL_MAX) && b0 + off - PL_MAX < slots) {
+                const uint32_t v = idx_in[b0 + off - PL_MAX];
+                s_r2[off] = (v & PL_DEAD_BIT) ? 0u : rank2_of(rank, v, n, h);
+            }
         }
     }
     __syncthreads();
@@ -744,7 +770,7 @@ __global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__res
         const uint32_t m = meta_in[a];
         const uint32_t gs = static_cast<uint32_t>(a) - (m & PL_OFF_MASK), ge = gs + ((m >> 9) & PL_OFF_MASK) + 1u;
         const uint32_t mine = my_r2[k];
-        const uint32_t base = static_cast<uint32_t>(LS_MAX) - static_cast<uint32_t>(b0);  // LDS index of slot b = b + base (mod 2^32)
+        const uint32_t base = static_cast<uint32_t>(PL_MAX) - static_cast<uint32_t>(b0);  // LDS index of slot b = b + base (mod 2^32)
         uint32_t less = 0, eq_before = 0, eq = 0;
         for (uint32_t b = gs; b < ge; ++b) {
             const uint32_t v = s_r2[b + base];
@@ -845,24 +871,15 @@ __global__ __launch_bounds__(RR_BLOCK) void k_plateau_compact(const uint32_t *__
     }
 }
 
-// enqueue the classification of the groups rerank() just produced and read back (active, groups, big slots)
-// all_small: every group of the list that was just reranked was small (<= LS_MAX); its children are subsets, so nothing can be
-// big any more and the classification kernels are skipped for good.
+// enqueue the classification of the groups rerank() just produced and read back (active, groups, big slots, slots in groups > PL_MAX)
 int classify_and_read(dk_ctx *ctx, size_t max_groups, uint32_t *gstart, uint32_t *bigstart, size_t *active, size_t *groups, size_t *nbig,
-                      bool all_small = false) {
+                      size_t *nmedium) {
     hipStream_t st = ctx->stream;
-    if (all_small) {
-        DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        DK_HIP(ctx, hipStreamSynchronize(st));
-        *active = ctx->h_mail[0];
-        *groups = ctx->h_mail[1];
-        *nbig = 0;
-        return DK_OK;
-    }
     const size_t mark = ctx->ws_mark();
     const size_t ntiles = div_up(max_groups + 1, BG_TILE);
     uint32_t *part = ctx->ws_alloc<uint32_t>(ntiles);
     if (!part) return DK_E_NOMEM;
+    DK_HIP(ctx, hipMemsetAsync(ctx->d_mail + 3, 0, sizeof(uint32_t), st));
     {
         LaunchScope ls(ctx, K_BIG_CLASSIFY, 8.0 * max_groups);
         k_big_reduce<<<dim3(ntiles), dim3(256), 0, st>>>(gstart, ctx->d_mail, part);
@@ -870,11 +887,12 @@ int classify_and_read(dk_ctx *ctx, size_t max_groups, uint32_t *gstart, uint32_t
         k_big_apply<<<dim3(ntiles), dim3(256), 0, st>>>(gstart, ctx->d_mail, part, bigstart);
     }
     DK_HIP(ctx, hipGetLastError());
-    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     DK_HIP(ctx, hipStreamSynchronize(st));
     *active = ctx->h_mail[0];
     *groups = ctx->h_mail[1];
     *nbig = ctx->h_mail[2];
+    *nmedium = ctx->h_mail[3];
     ctx->ws_release(mark);
     return DK_OK;
 }
@@ -1007,7 +1025,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     //    one bucketed scatter for the whole sort instead of one here plus tens of millions of random rank stores in the next round.
     //    DK_RANKS_FIRST=1 (A/B and test hook): the rank array is built right here and the first round is a doubling round (not on the
     //    probe's short-prefix path, which never has ranks this early).
-    size_t active = 0, groups = 0, nbig = 0;
+    size_t active = 0, groups = 0, nbig = 0, nmedium = 0;
     static const bool bucketed = [] { const char *e = getenv("DK_BUCKETED"); return !(e && e[0] == '0'); }();
     static const bool ranks_first_env = [] { const char *e = getenv("DK_RANKS_FIRST"); return e && e[0] == '1'; }();
     const bool ranks_first = ranks_first_env && !short_prefix;
@@ -1024,7 +1042,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     } else {
         DK_TRY(rerank(ctx, keys, vals, nullptr, n, nullptr, rank, d_sa, vals_alt, pos, gid, gstart, nullptr, true, nullptr, first_bc));
     }
-    DK_TRY(classify_and_read(ctx, n / 2, gstart, bigstart, &active, &groups, &nbig));
+    DK_TRY(classify_and_read(ctx, n / 2, gstart, bigstart, &active, &groups, &nbig, &nmedium));
     std::swap(vals, vals_alt);  // vals = suffix indices of the active list
 
     uint64_t h = static_cast<uint64_t>(spk_sort);
@@ -1074,19 +1092,20 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
             DK_HIP(ctx, hipGetLastError());
         }
         // keys / vals_alt (/ sym_alt) now hold every group sorted by its secondary key in its own slot range
-        size_t next_active = 0, next_groups = 0, next_big = 0;
+        size_t next_active = 0, next_groups = 0, next_big = 0, next_medium = 0;
         const BwtCarry bc{0, carry_bwt ? d_bwt : nullptr, nullptr, d_origin, sym_alt, sym};
         DK_TRY(rerank(ctx, keys, vals_alt, pos, active, gid, have_ranks ? rank : nullptr, d_sa, vals, pos_alt, gid_alt, gstart, nullptr, false,
                       nullptr, bc));
-        DK_TRY(classify_and_read(ctx, active / 2, gstart, bigstart, &next_active, &next_groups, &next_big, nbig == 0));
+        DK_TRY(classify_and_read(ctx, active / 2, gstart, bigstart, &next_active, &next_groups, &next_big, &next_medium));
         std::swap(pos, pos_alt);
         std::swap(gid, gid_alt);
         if (trace)
-            fprintf(stderr, "[dk] round %u h=%llu%s slots=%zu big=%zu key bits=%d (big %d+%d) -> active=%zu groups=%zu big=%zu\n", ctx->stats.rounds,
-                    (unsigned long long)h, tsym > 0 ? " (text)" : "", active, nbig, kbits, bsbits, kb, next_active, next_groups, next_big);
+            fprintf(stderr, "[dk] round %u h=%llu%s slots=%zu big=%zu key bits=%d (big %d+%d) -> active=%zu groups=%zu big=%zu (>%d: %zu)\n", ctx->stats.rounds,
+                    (unsigned long long)h, tsym > 0 ? " (text)" : "", active, nbig, kbits, bsbits, kb, next_active, next_groups, next_big, PL_MAX, next_medium);
         active = next_active;
         groups = next_groups;
         nbig = next_big;
+        nmedium = next_medium;
         ctx->stats.rounds += 1;
         return DK_OK;
     };
@@ -1116,7 +1135,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
 
     // 5c. doubling rounds: the general form while big groups exist, ...
     static const bool plateau_enabled = [] { const char *e = getenv("DK_PLATEAU"); return !(e && e[0] == '0'); }();
-    while (active > 0 && (nbig > 0 || !plateau_enabled)) {
+    while (active > 0 && (nmedium > 0 || !plateau_enabled)) {
         if (ctx->stats.rounds > 44) return ctx->fail(DK_E_INTERNAL, "suffix_array: no convergence after 44 rounds");
         DK_TRY(run_round(0, nullptr));
         h *= 2;
