@@ -18,6 +18,7 @@ Extensions beyond the reference (whole file = one block, read into memory, one t
 """
 import argparse
 import os
+import time
 import struct
 import subprocess
 import sys
@@ -27,6 +28,7 @@ import queue
 import numpy as np
 
 EXTENSION = "dark"
+STATS = {}  # --stats: when the library and its context were ready (imports, workspace allocation done)
 FOOTER_MAGIC = b"DKIX"
 DUMP_MODELS = ("raw", "rawdc")
 
@@ -116,9 +118,12 @@ def _encode_blocks(path, model, block_size, device, first_block, step, total_blo
     import torch
     from .context import Context
     torch.cuda.set_device(device)
-    batch = max(2, host_threads)
+    # blocks per batch: as many as 1.5 GB of HBM hold (at least two, at most 16 per coding thread): the longer the batch, the smaller
+    # the share of its tail, where coding threads run out of blocks
+    batch = int(max(2, min(16 * host_threads, (3 << 29) // max(1, block_size))))
     q = queue.Queue(maxsize=1)  # one batch being read ahead while one is being encoded
     with open(path, "rb") as f, Context(block_size, device) as ctx:
+        STATS["t_ready"] = time.perf_counter()
         t = threading.Thread(target=_reader, args=(f, block_size, first_block, step, total_blocks, batch, q, force, device), daemon=True)
         t.start()
         while True:
@@ -270,7 +275,6 @@ def _decode_records_batched(path, model, device, offsets, end, which, out_write,
     import torch
     from .context import Context
     torch.cuda.set_device(device)
-    batch = max(2, host_threads)
     bounds = offsets + [end]
     with open(path, "rb") as f:
         sizes = []
@@ -279,7 +283,9 @@ def _decode_records_batched(path, model, device, offsets, end, which, out_write,
             sizes.append(struct.unpack("<I", f.read(4))[0])
         if not sizes:
             return
+        batch = int(max(2, min(16 * host_threads, (3 << 29) // max(sizes))))
         with Context(max(sizes), device) as ctx:
+            STATS["t_ready"] = time.perf_counter()
             for lo in range(0, len(which), batch):
                 ks = which[lo:lo + batch]
                 ns = sizes[lo:lo + batch]
@@ -377,7 +383,6 @@ def main(argv=None):
     decode = has_extension(args.file, EXTENSION)           # main.rs:56: direction by extension
     if args.worker:
         return _worker_decode(args) if decode else _worker_encode(args)
-    import time
     t0 = time.perf_counter()
     if decode:
         out = decode_file(args.file, args.model, args.device, args.gpus, args.host_threads, args.devices)
@@ -387,7 +392,8 @@ def main(argv=None):
     if args.stats:  # wall time of the work itself (interpreter start and imports of this front end excluded) and this process's peak RSS
         import json
         import resource
-        print(json.dumps({"seconds": round(time.perf_counter() - t0, 3), "input_bytes": os.path.getsize(args.file),
+        t1 = time.perf_counter()
+        print(json.dumps({"seconds": round(t1 - t0, 3), "seconds_after_setup": round(t1 - STATS.get("t_ready", t0), 3), "input_bytes": os.path.getsize(args.file),
                           "output_bytes": os.path.getsize(out), "peak_rss_bytes": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss * 1024}),
               file=sys.stderr)
 

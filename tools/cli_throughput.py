@@ -63,6 +63,8 @@ def main():
                           "encode_s": round(t_enc, 2), "encode_MBps": round(total / t_enc / 1e6, 1), "decode_s": round(t_dec, 2),
                           "decode_MBps": round(total / t_dec / 1e6, 1),
                           "encode_inside": in_enc, "encode_MBps_inside": round(total / in_enc["seconds"] / 1e6, 1) if in_enc else None,
+                          "encode_MBps_after_setup": round(total / in_enc["seconds_after_setup"] / 1e6, 1) if in_enc else None,
+                          "decode_MBps_after_setup": round(total / in_dec["seconds_after_setup"] / 1e6, 1) if in_dec else None,
                           "decode_inside": in_dec, "decode_MBps_inside": round(total / in_dec["seconds"] / 1e6, 1) if in_dec else None, "packed_bytes": os.path.getsize(packed), "roundtrip_ok": ok,
                           "peak_rss_bytes_children": rss_dec, "peak_rss_in_blocks": round(rss_dec / args.block_bytes, 2),
                           "note": "wall time of the whole CLI process (python start, library load, context creation, file I/O included); "
