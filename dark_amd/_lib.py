@@ -50,6 +50,9 @@ SIGNATURES = {
     "dk_dev_block_encode": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _szp]),
     "dk_dev_block_decode": (_i, [_vp, _i, _vp, _sz, _sz, _vp]),
     "dk_dev_batch_encode": (_i, [_vp, _i, _sz, _vp, _vp, _vp, _vp, _vp, _i]),
+    "dk_batch_begin": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "dk_batch_push": (_i, [_vp, _vp, _sz, _vp, _sz, _szp]),
+    "dk_batch_finish": (_i, [_vp]),
     "dk_dev_batch_decode": (_i, [_vp, _i, _sz, _vp, _vp, _vp, _vp, _i]),
     "dk_multi_block_encode": (_i, [_vp, _i, _i, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
     "dk_multi_block_decode": (_i, [_vp, _i, _i, _sz, _vp, _vp, _vp, _vp, _i, _vp, _sz]),

@@ -10,8 +10,8 @@ one block is byte-for-byte what the reference writes: [u32 LE n][coded stream] (
 Extensions beyond the reference (whole file = one block, read into memory, one thread):
   -b BYTES   cut the input into blocks; records [u32 LE n][stream] are concatenated, each byte-identical to a single-block run on that
              block, followed by an index footer (record offsets) so that decoding can be batched and spread over GPUs.  The reference
-             reads such a file as its first block only.  Blocks are STREAMED: one block of input is in host memory at a time, batches of
-             blocks live in HBM and go through dk_dev_batch_encode (GPU stages of block i+1 overlap the host coding of earlier blocks).
+             reads such a file as its first block only.  Blocks are STREAMED: one block of input is in host memory at a time; each goes
+             through dk_batch_push as soon as it is in HBM (file reading, upload, GPU stages and the host coding of earlier blocks overlap).
   --gpus G   block b -> GPU b mod G, one worker process per GPU; the parent never touches a GPU and stitches the records in order.
   --force    encode blocks that contain byte 0xFF.  The reference's header cannot carry that symbol (src/block/dc.rs:57,60,73,127):
              it writes such an archive without complaint and can never decode it.  This front end refuses unless --force is given.
@@ -91,54 +91,68 @@ def _write_block(ctx, model, block, out, first, force):
         out.write(ctx.block_encode(model, block))         # main.rs:104-113
 
 
-# ---- streamed, batched encode on one GPU ---------------------------------------------------------------------------------------------
-def _reader(f, block_size, first_block, step, total_blocks, batch, q, force, device):
-    """reads block indices first_block, first_block+step, ... one at a time, uploads each to HBM, hands over batches of device tensors"""
+# ---- streamed, pipelined encode on one GPU ---------------------------------------------------------------------------------------------
+def _reader(f, block_size, first_block, step, total_blocks, q, force, device):
+    """reads blocks first_block, first_block+step, ... one at a time and uploads each to HBM; at most two are waiting to be pushed"""
     import torch
     try:
-        cur = []
         for b in range(first_block, total_blocks, step):
             f.seek(b * block_size)
             block = np.fromfile(f, dtype=np.uint8, count=block_size)  # ONE block of input in host memory
             _check_ff(block, force, "block %d" % b)
-            cur.append((b, len(block), torch.from_numpy(block).to("cuda:%d" % device)))
+            q.put((b, len(block), torch.from_numpy(block).to("cuda:%d" % device)))
             del block
-            if len(cur) == batch:
-                q.put(cur)
-                cur = []
-        if cur:
-            q.put(cur)
         q.put(None)
     except BaseException as e:  # noqa: BLE001 -- handed to the consumer, which re-raises
         q.put(e)
 
 
 def _encode_blocks(path, model, block_size, device, first_block, step, total_blocks, out, index, force, host_threads):
-    """encode blocks first_block, first_block+step, ... of `path` in order into `out`; index gets (block number, record length)"""
+    """encode blocks first_block, first_block+step, ... of `path` in order into `out`; index gets (block number, record length).
+    Every block goes through dk_batch_push as soon as it is in HBM: its device stages run at once, its coding on one of the host threads;
+    file reading, upload, GPU stages and coding all overlap.  Records are written out every `flush_every` blocks."""
     import torch
     from .context import Context
     torch.cuda.set_device(device)
-    # blocks per batch: as many as 1.5 GB of HBM hold (at least two, at most 16 per coding thread): the longer the batch, the smaller
-    # the share of its tail, where coding threads run out of blocks
-    batch = int(max(2, min(16 * host_threads, (3 << 29) // max(1, block_size))))
-    q = queue.Queue(maxsize=1)  # one batch being read ahead while one is being encoded
+    flush_every = int(max(2 * host_threads, min(256, (1 << 32) // max(1, block_size))))  # at most about 4 GB of input between flushes
+    q = queue.Queue(maxsize=2)
     with open(path, "rb") as f, Context(block_size, device) as ctx:
         STATS["t_ready"] = time.perf_counter()
-        t = threading.Thread(target=_reader, args=(f, block_size, first_block, step, total_blocks, batch, q, force, device), daemon=True)
+        t = threading.Thread(target=_reader, args=(f, block_size, first_block, step, total_blocks, q, force, device), daemon=True)
         t.start()
+        batch, pending = None, []
+
+        def flush():
+            nonlocal batch, pending
+            if batch is None:
+                return
+            streams = batch.finish()
+            for (b, n), s in zip(pending, streams):
+                out.write(struct.pack("<I", n))
+                out.write(memoryview(s))
+                index.append((b, 4 + len(s)))
+            batch, pending = None, []
+
         while True:
             item = q.get()
             if item is None:
                 break
             if isinstance(item, BaseException):
+                if batch is not None:
+                    try:
+                        batch.finish()
+                    except Exception:  # noqa: BLE001 -- the reader's error is the one to report
+                        pass
                 raise item
-            sizes = [n for _, n, _ in item]
-            streams = ctx.dev_batch_encode(model, [d for _, _, d in item], sizes, host_threads)
-            for (b, n, _), s in zip(item, streams):
-                out.write(struct.pack("<I", n))
-                out.write(memoryview(s))
-                index.append((b, 4 + len(s)))
-            del item, streams
+            b, n, d = item
+            if batch is None:
+                batch = ctx.batch_begin(model, host_threads)
+            batch.push(d, n)
+            pending.append((b, n))
+            del d, item
+            if len(pending) >= flush_every:
+                flush()
+        flush()
         t.join()
 
 

@@ -207,6 +207,10 @@ class Context:
         self._ck(self._lib.dk_dev_batch_encode(self._h, model_id(model), count, ptrs, ns, optrs, caps, lens, int(host_threads)))
         return [o[:lens[i]] for i, o in enumerate(outs)]
 
+    def batch_begin(self, model, host_threads=8):
+        """streaming form of dev_batch_encode: returns a Batch; push(d_in, n) per block as it arrives, then finish() -> list of streams"""
+        return Batch(self, model, host_threads)
+
     def dev_batch_decode(self, model, streams, sizes, d_outs, host_threads=8):
         count = len(streams)
         keep = [as_u8(x) for x in streams]
@@ -247,6 +251,30 @@ class Context:
         vals = np.ascontiguousarray(vals, dtype=np.uint32).copy()
         self._ck(self._lib.dk_dbg_sort_pairs(self._h, _ptr(keys), _ptr(vals), len(keys), begin_bit, end_bit))
         return keys, vals
+
+
+class Batch:
+    """dk_batch_begin / _push / _finish: the pipelined encoder fed one block at a time"""
+
+    def __init__(self, ctx, model, host_threads):
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        ctx._ck(ctx._lib.dk_batch_begin(ctx._h, model_id(model), int(host_threads), C.byref(self._h)))
+        self._outs, self._lens = [], []
+
+    def push(self, d_in, n):
+        """device stages of one block now (d_in may be reused when this returns), coding in the background"""
+        _inputs_ready(d_in)
+        out = np.empty(2 * int(n) + 4096, dtype=np.uint8)  # virtual until written: only the coded bytes become resident
+        ln = C.c_size_t(0)
+        self._outs.append(out)
+        self._lens.append(ln)
+        self._ctx._ck(self._ctx._lib.dk_batch_push(self._h, _ptr(d_in), int(n), _ptr(out), len(out), C.byref(ln)))
+
+    def finish(self):
+        h, self._h = self._h, None
+        self._ctx._ck(self._ctx._lib.dk_batch_finish(h))
+        return [o[:ln.value] for o, ln in zip(self._outs, self._lens)]
 
 
 def multi_block_encode(model, blocks, devices, host_threads_per_gpu=4):

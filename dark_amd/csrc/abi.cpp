@@ -286,29 +286,24 @@ int dk_dev_block_decode(dk_ctx *ctx, int model_id, const uint8_t *in, size_t in_
 // Batch of independent blocks on one GPU: the device stages run block after block on the context's stream while a pool of host
 // threads codes the distance streams of the blocks already done (the "one block per core, pipelined against the GPU work of
 // the next block" deployment of SURVEY.md section 7.8).  Every out[i] is byte-identical to a dk_dev_block_encode of block i.
-int dk_dev_batch_encode(dk_ctx *ctx, int model_id, size_t count, const uint8_t *const *d_in, const size_t *n, uint8_t *const *out,
-                        const size_t *out_cap, size_t *out_len, int host_threads) {
-    DK_TRY(begin_call(ctx));
-    ScopedCall sc(ctx);
-    if (!d_in || !n || !out || !out_cap || !out_len || count == 0) return ctx->fail(DK_E_ARG, "null pointer or empty batch");
-    if (model_max_block(model_id) == 0) return ctx->fail(DK_E_MODEL, "unknown model id %d", model_id);
-    for (size_t i = 0; i < count; ++i) {
-        if (!d_in[i] || !out[i]) return ctx->fail(DK_E_ARG, "null pointer in block %zu", i);
-        DK_TRY(check_n(ctx, n[i]));
-        if (n[i] > model_max_block(model_id)) return ctx->fail(DK_E_MODEL, "model %d cannot code a block of %zu bytes", model_id, n[i]);
-    }
-    Timer t;
-    const size_t workers = static_cast<size_t>(std::max(1, std::min<int>(host_threads, static_cast<int>(count))));
-    const size_t nslots = workers + 1;
-    struct Job { size_t block; int slot; ForwardResult fr; };
+// Streaming form: dk_batch_begin starts the coding threads, dk_batch_push runs the device stages of one more block on the calling
+// thread (it waits while every staging slot is busy) and queues its coding, dk_batch_finish waits for the coders.
+}  // extern "C"
+
+struct dk_batch {
+    dk_ctx *ctx = nullptr;
+    int model_id = 0;
+    struct Job { size_t block; int slot; ForwardResult fr; size_t n; uint8_t *out; size_t cap; size_t *out_len; };
     std::mutex mu;
     std::condition_variable cv_job, cv_slot;
     std::deque<Job> queue;
     std::vector<int> free_slots;
-    for (size_t k = 0; k < nslots; ++k) free_slots.push_back(static_cast<int>(k));
+    std::vector<std::thread> pool;
     bool done = false;
-    std::vector<int> rcs(count, DK_OK);
-    auto worker = [&] {
+    size_t pushed = 0;
+    int first_rc = DK_OK;
+    size_t first_bad = 0;
+    void worker() {
         for (;;) {
             Job job;
             {
@@ -319,50 +314,97 @@ int dk_dev_batch_encode(dk_ctx *ctx, int model_id, size_t count, const uint8_t *
                 queue.pop_front();
             }
             DcStream s;
-            s.n = n[job.block]; s.init = job.fr.init; s.dist = job.fr.dist; s.sym = job.fr.sym; s.rank = job.fr.rank;
+            s.n = job.n; s.init = job.fr.init; s.dist = job.fr.dist; s.sym = job.fr.sym; s.rank = job.fr.rank;
             s.run_end = job.fr.run_end; s.m = job.fr.m; s.origin = job.fr.origin;
-            rcs[job.block] = encode_block_stream(model_id, s, out[job.block], out_cap[job.block], &out_len[job.block], 1);
+            const int rc = encode_block_stream(model_id, s, job.out, job.cap, job.out_len, 1);
             {
                 std::lock_guard<std::mutex> lk(mu);
+                if (rc != DK_OK && first_rc == DK_OK) { first_rc = rc; first_bad = job.block; }
                 free_slots.push_back(job.slot);
             }
             cv_slot.notify_one();
         }
-    };
-    std::vector<std::thread> pool;
-    for (size_t w = 0; w < workers; ++w) pool.emplace_back(worker);
-    int rc = DK_OK;
-    for (size_t i = 0; i < count && rc == DK_OK; ++i) {
-        int slot;
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv_slot.wait(lk, [&] { return !free_slots.empty(); });
-            slot = free_slots.back();
-            free_slots.pop_back();
-        }
-        Job job;
-        job.block = i;
-        job.slot = slot;
-        ctx->ws_reset();
-        rc = forward_to_stream(ctx, d_in[i], n[i], model_id == DK_MODEL_RAWDC, &job.fr, slot);
-        if (rc != DK_OK) break;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            queue.push_back(job);
-        }
-        cv_job.notify_one();
+    }
+};
+
+extern "C" {
+
+int dk_batch_begin(dk_ctx *ctx, int model_id, int host_threads, dk_batch **out) {
+    DK_TRY(begin_call(ctx));
+    if (!out) return ctx->fail(DK_E_ARG, "null pointer");
+    *out = nullptr;
+    if (model_max_block(model_id) == 0) return ctx->fail(DK_E_MODEL, "unknown model id %d", model_id);
+    dk_batch *b = new (std::nothrow) dk_batch();
+    if (!b) return DK_E_NOMEM;
+    b->ctx = ctx;
+    b->model_id = model_id;
+    const size_t workers = static_cast<size_t>(std::max(1, host_threads));
+    for (size_t k = 0; k < workers + 1; ++k) b->free_slots.push_back(static_cast<int>(k));
+    for (size_t w = 0; w < workers; ++w) b->pool.emplace_back([b] { b->worker(); });
+    *out = b;
+    return DK_OK;
+}
+
+int dk_batch_push(dk_batch *b, const uint8_t *d_in, size_t n, uint8_t *out, size_t out_cap, size_t *out_len) {
+    if (!b) return DK_E_ARG;
+    dk_ctx *ctx = b->ctx;
+    if (!d_in || !out || !out_len) return ctx->fail(DK_E_ARG, "null pointer in block %zu", b->pushed);
+    DK_TRY(check_n(ctx, n));
+    if (n > model_max_block(b->model_id)) return ctx->fail(DK_E_MODEL, "model %d cannot code a block of %zu bytes", b->model_id, n);
+    if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(DK_E_HIP, "hipSetDevice(%d) failed", ctx->device);
+    int slot;
+    {
+        std::unique_lock<std::mutex> lk(b->mu);
+        b->cv_slot.wait(lk, [&] { return !b->free_slots.empty(); });
+        slot = b->free_slots.back();
+        b->free_slots.pop_back();
+    }
+    dk_batch::Job job;
+    job.block = b->pushed++;
+    job.slot = slot;
+    job.n = n; job.out = out; job.cap = out_cap; job.out_len = out_len;
+    ctx->ws_reset();
+    const int rc = forward_to_stream(ctx, d_in, n, b->model_id == DK_MODEL_RAWDC, &job.fr, slot);
+    if (ctx->profiling) ctx->prof_collect();
+    if (rc != DK_OK) {
+        std::lock_guard<std::mutex> lk(b->mu);
+        b->free_slots.push_back(slot);
+        return rc;
     }
     {
-        std::lock_guard<std::mutex> lk(mu);
-        done = true;
+        std::lock_guard<std::mutex> lk(b->mu);
+        b->queue.push_back(job);
     }
-    cv_job.notify_all();
-    for (auto &th : pool) th.join();
-    ctx->stats.ms_total = t.ms();
-    if (rc != DK_OK) return rc;
-    for (size_t i = 0; i < count; ++i)
-        if (rcs[i] != DK_OK) return ctx->fail(rcs[i], "entropy stage of block %zu failed (%d)", i, rcs[i]);
+    b->cv_job.notify_one();
     return DK_OK;
+}
+
+int dk_batch_finish(dk_batch *b) {
+    if (!b) return DK_E_ARG;
+    {
+        std::lock_guard<std::mutex> lk(b->mu);
+        b->done = true;
+    }
+    b->cv_job.notify_all();
+    for (auto &th : b->pool) th.join();
+    int rc = b->first_rc;
+    if (rc != DK_OK) rc = b->ctx->fail(rc, "entropy stage of block %zu failed (%d)", b->first_bad, rc);
+    delete b;
+    return rc;
+}
+
+int dk_dev_batch_encode(dk_ctx *ctx, int model_id, size_t count, const uint8_t *const *d_in, const size_t *n, uint8_t *const *out,
+                        const size_t *out_cap, size_t *out_len, int host_threads) {
+    if (!ctx) return DK_E_ARG;
+    if (!d_in || !n || !out || !out_cap || !out_len || count == 0) { ctx->err.clear(); return ctx->fail(DK_E_ARG, "null pointer or empty batch"); }
+    Timer t;
+    dk_batch *b = nullptr;
+    DK_TRY(dk_batch_begin(ctx, model_id, std::max(1, std::min<int>(host_threads, static_cast<int>(count))), &b));
+    int rc = DK_OK;
+    for (size_t i = 0; i < count && rc == DK_OK; ++i) rc = dk_batch_push(b, d_in[i], n[i], out[i], out_cap[i], &out_len[i]);
+    const int rc2 = dk_batch_finish(b);
+    ctx->stats.ms_total = t.ms();
+    return rc != DK_OK ? rc : rc2;
 }
 
 // Inverse of dk_dev_batch_encode: host threads decode the streams (range decoder + dc::decode, serial per block) into pinned

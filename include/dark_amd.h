@@ -120,6 +120,14 @@ int dk_dev_block_encode(dk_ctx *ctx, int model_id, const uint8_t *d_in, size_t n
  * Encoder::new, src/block/dc.rs:30-37,53).  out[i] / out_len[i] are exactly what dk_dev_block_encode gives for block i. */
 int dk_dev_batch_encode(dk_ctx *ctx, int model_id, size_t count, const uint8_t *const *d_in, const size_t *n,
                         uint8_t *const *out, const size_t *out_cap, size_t *out_len, int host_threads);
+/* The same pipeline fed one block at a time (blocks that arrive from a file): begin starts `host_threads` coding threads;
+ * push runs the device stages of one more block on the calling thread -- on return d_in may be reused -- and queues its coding
+ * (it waits while every staging slot is busy); *out_len is written when that block's coding ends; finish waits for all coders,
+ * frees the batch and returns the first failure.  Between begin and finish the context serves this batch only. */
+typedef struct dk_batch dk_batch;
+int dk_batch_begin(dk_ctx *ctx, int model_id, int host_threads, dk_batch **out);
+int dk_batch_push(dk_batch *batch, const uint8_t *d_in, size_t n, uint8_t *out, size_t out_cap, size_t *out_len);
+int dk_batch_finish(dk_batch *batch);
 /* inverse of dk_dev_batch_encode: host threads decode the streams while the GPU inverts the BWTs that are ready */
 int dk_dev_batch_decode(dk_ctx *ctx, int model_id, size_t count, const uint8_t *const *in, const size_t *in_len, const size_t *n,
                         uint8_t *const *d_out, int host_threads);
