@@ -297,21 +297,46 @@ def _decode_records_batched(path, model, device, offsets, end, which, out_write,
             sizes.append(struct.unpack("<I", f.read(4))[0])
         if not sizes:
             return
-        batch = int(max(2, min(16 * host_threads, (3 << 29) // max(sizes))))
+        batch = int(max(2, min(4 * host_threads, (1 << 30) // max(sizes))))  # two batches of outputs live in HBM at a time
         with Context(max(sizes), device) as ctx:
             STATS["t_ready"] = time.perf_counter()
-            for lo in range(0, len(which), batch):
-                ks = which[lo:lo + batch]
-                ns = sizes[lo:lo + batch]
-                streams = []
-                for k in ks:
-                    f.seek(offsets[k] + 4)
-                    streams.append(np.fromfile(f, dtype=np.uint8, count=bounds[k + 1] - offsets[k] - 4))
-                d_outs = [torch.empty(n, dtype=torch.uint8, device="cuda:%d" % device) for n in ns]
-                ctx.dev_batch_decode(model, streams, ns, d_outs, host_threads)
-                for k, d in zip(ks, d_outs):
-                    out_write(k, d.cpu().numpy().tobytes())
-                del d_outs, streams
+            # a writer thread downloads and writes the blocks of one batch while the next batch is being decoded
+            wq = queue.Queue(maxsize=1)
+            werr = []
+
+            def writer():
+                while True:
+                    item = wq.get()
+                    if item is None:
+                        return
+                    try:
+                        if not werr:
+                            for k, d in zip(*item):
+                                out_write(k, d.cpu().numpy().tobytes())
+                    except BaseException as e:  # noqa: BLE001 -- re-raised by the main thread
+                        werr.append(e)
+
+            wt = threading.Thread(target=writer, daemon=True)
+            wt.start()
+            try:
+                for lo in range(0, len(which), batch):
+                    ks = which[lo:lo + batch]
+                    ns = sizes[lo:lo + batch]
+                    streams = []
+                    for k in ks:
+                        f.seek(offsets[k] + 4)
+                        streams.append(np.fromfile(f, dtype=np.uint8, count=bounds[k + 1] - offsets[k] - 4))
+                    d_outs = [torch.empty(n, dtype=torch.uint8, device="cuda:%d" % device) for n in ns]
+                    ctx.dev_batch_decode(model, streams, ns, d_outs, host_threads)
+                    wq.put((ks, d_outs))
+                    del d_outs, streams
+                    if werr:
+                        break
+            finally:
+                wq.put(None)
+                wt.join()
+            if werr:
+                raise werr[0]
 
 
 def decode_file(path, model, device=0, gpus=1, host_threads=0, devices=None):

@@ -45,13 +45,17 @@ def main():
     ap.add_argument("--model", default="dark")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--devices", default="")
+    ap.add_argument("--repeat", type=int, default=1, help="write the generated blocks this many times (bigger file, same generation time)")
     args = ap.parse_args()
     from dark_amd import datagen
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
         src = os.path.join(d, "enwik9_like.txt")
         with open(src, "wb") as f:
-            for b in range(args.blocks):
-                datagen.wiki_like(args.block_bytes, 40 + b).tofile(f)
+            made = [datagen.wiki_like(args.block_bytes, 40 + b) for b in range(args.blocks)]
+            for _ in range(args.repeat):
+                for blk in made:
+                    blk.tofile(f)
+            del made
         total = os.path.getsize(src)
         extra = ["--gpus", str(args.gpus)] + (["--devices", args.devices] if args.devices else [])
         cmd = [sys.executable, "-m", "dark_amd.cli", "--stats", "-m", args.model, "-b", str(args.block_bytes)] + extra
@@ -59,14 +63,14 @@ def main():
         packed = os.path.join(d, "enwik9_like.dark")
         t_dec, in_dec, rss_dec = run([sys.executable, "-m", "dark_amd.cli", "--stats", "-m", args.model] + extra + [packed], d)
         ok = sha(os.path.join(d, "enwik9_like.orig")) == sha(src)
-        print(json.dumps({"file_bytes": total, "blocks": args.blocks, "block_bytes": args.block_bytes, "model": args.model, "gpus": args.gpus,
+        print(json.dumps({"file_bytes": total, "blocks": args.blocks * args.repeat, "block_bytes": args.block_bytes, "model": args.model, "gpus": args.gpus,
                           "encode_s": round(t_enc, 2), "encode_MBps": round(total / t_enc / 1e6, 1), "decode_s": round(t_dec, 2),
                           "decode_MBps": round(total / t_dec / 1e6, 1),
                           "encode_inside": in_enc, "encode_MBps_inside": round(total / in_enc["seconds"] / 1e6, 1) if in_enc else None,
                           "encode_MBps_after_setup": round(total / in_enc["seconds_after_setup"] / 1e6, 1) if in_enc else None,
                           "decode_MBps_after_setup": round(total / in_dec["seconds_after_setup"] / 1e6, 1) if in_dec else None,
                           "decode_inside": in_dec, "decode_MBps_inside": round(total / in_dec["seconds"] / 1e6, 1) if in_dec else None, "packed_bytes": os.path.getsize(packed), "roundtrip_ok": ok,
-                          "peak_rss_bytes_children": rss_dec, "peak_rss_in_blocks": round(rss_dec / args.block_bytes, 2),
+                          "peak_rss_bytes_children": rss_dec, "peak_rss_in_blocks": round(rss_dec / args.block_bytes, 2), "input_unique_blocks": args.blocks,
                           "note": "wall time of the whole CLI process (python start, library load, context creation, file I/O included); "
                                   "RSS includes the library's pinned staging of the distance streams (about 2.5 bytes per input byte per "
                                   "block in flight), not only the CLI's own buffers"}))
