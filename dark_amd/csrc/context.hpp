@@ -44,6 +44,8 @@ enum KernelSlot : int {
     K_PLATEAU_SORT,
     K_PLATEAU_RANKS,   // k_plateau_ranks, k_to_inplace, k_plateau_count/_scan/_compact
     K_RADIX_SORT_SMALL,
+    K_RADIX_HIST_TEXT,     // k_radix_hist<false, true>: first pass, digits straight from the text (1 B per key)
+    K_RADIX_SCATTER_TEXT,  // k_radix_scatter<false, true>: first pass, keys built from the text (13 B per pair)
     K_SLOT_COUNT
 };
 static_assert(K_SLOT_COUNT <= DK_NUM_KERNEL_SLOTS, "grow DK_NUM_KERNEL_SLOTS");

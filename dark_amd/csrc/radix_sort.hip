@@ -467,7 +467,7 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
     hipStream_t st = ctx->stream;
     for (int shift = begin_bit; shift < end_bit; shift += 8) {
         {
-            LaunchScope ls(ctx, K_RADIX_HIST, (text && shift == begin_bit ? 1.0 : 8.0) * count);
+            LaunchScope ls(ctx, text && shift == begin_bit ? K_RADIX_HIST_TEXT : K_RADIX_HIST, (text && shift == begin_bit ? 1.0 : 8.0) * count);
             if (text && shift == begin_bit)
                 k_radix_hist<false, true><<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(nullptr, nullptr, nullptr, count, shift, tile_hist, *text);
             else
@@ -484,7 +484,7 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
             }
         }
         {
-            LaunchScope ls(ctx, K_RADIX_SCATTER, (text && shift == begin_bit ? 13.0 : 24.0) * count);
+            LaunchScope ls(ctx, text && shift == begin_bit ? K_RADIX_SCATTER_TEXT : K_RADIX_SCATTER, (text && shift == begin_bit ? 13.0 : 24.0) * count);
             static const bool xcd = [] { const char *e = getenv("DK_XCD"); return !(e && e[0] == '0'); }();
             const size_t grid = xcd ? 8 * div_up(ntiles, 8) : ntiles;
             if (text && shift == begin_bit)

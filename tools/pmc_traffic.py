@@ -37,8 +37,14 @@ SLOT_OF = {"k_radix_scan_small": "k_radix_scan", "k_radix_scan_a": "k_radix_scan
 
 
 def short(name):
-    m = re.search(r"(k_[a-z0-9_]+)", name)
-    return m.group(1) if m else None
+    m = re.search(r"(k_[a-z0-9_]+)(<[^>]*>)?", name)
+    if not m:
+        return None
+    k = m.group(1)
+    # the first pass of the initial sort is its own template instance (keys from the text) and its own dk_stats slot
+    if k in ("k_radix_hist", "k_radix_scatter") and m.group(2) and m.group(2).replace(" ", "") == "<false,true>":
+        k += "_text"
+    return k
 
 
 def collect(directory, counter):
