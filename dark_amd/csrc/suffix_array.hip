@@ -26,14 +26,38 @@ constexpr int RR_WAVES = RR_BLOCK / 64;
 constexpr int RR_IPT = 8;                    // slots per thread (contiguous)
 constexpr int RR_TILE = RR_BLOCK * RR_IPT;   // 2048 slots per workgroup
 
+// 16 bytes per load; 8 private copies of the histogram (copy = lane mod 8): text has a few very common bytes, and LDS atomics of one
+// wave instruction that hit the same counter are serialised
 __global__ __launch_bounds__(256) void k_sym_hist(const uint8_t *__restrict__ t, size_t n, uint32_t *__restrict__ hist) {
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+    __shared__ uint32_t h[8][256];
+    for (int i = threadIdx.x; i < 8 * 256; i += 256) (&h[0][0])[i] = 0;
     __syncthreads();
+    uint32_t *mine = h[threadIdx.x & 7];
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
-    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) atomicAdd(&h[t[i]], 1u);
+    const size_t i0 = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(t) & 15) == 0) {
+        const size_t n16 = n / 16;
+        const uint4 *t16 = reinterpret_cast<const uint4 *>(t);
+        for (size_t i = i0; i < n16; i += stride) {
+            const uint4 v = t16[i];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                atomicAdd(&mine[w[k] & 0xFFu], 1u);
+                atomicAdd(&mine[(w[k] >> 8) & 0xFFu], 1u);
+                atomicAdd(&mine[(w[k] >> 16) & 0xFFu], 1u);
+                atomicAdd(&mine[w[k] >> 24], 1u);
+            }
+        }
+        for (size_t i = n16 * 16 + i0; i < n; i += stride) atomicAdd(&mine[t[i]], 1u);
+    } else {
+        for (size_t i = i0; i < n; i += stride) atomicAdd(&mine[t[i]], 1u);
+    }
     __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+    uint32_t sum = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sum += h[c][threadIdx.x];
+    if (sum) atomicAdd(&hist[threadIdx.x], sum);
 }
 
 // key[i] = codes of T[i .. i+spk) packed big-endian (zero padded past the end), idx[i] = i.
@@ -487,12 +511,13 @@ __global__ __launch_bounds__(256) void k_big_reduce(const uint32_t *__restrict__
     uint32_t sum = 0, medium = 0;
     if (g0 < groups) {
 #pragma unroll
-        for (int j = 0; j < BG_IPT; ++j) {
-            sum += big_size(gstart, g0 + j, groups);
-            if (g0 + j < groups) {
-                const uint32_t sz = gstart[g0 + j + 1] - gstart[g0 + j];
-                medium += sz > static_cast<uint32_t>(PL_MAX) ? sz : 0u;
-            }
+        uint32_t prev = gstart[g0];
+        for (int j = 0; j < BG_IPT && g0 + j < groups; ++j) {
+            const uint32_t next = gstart[g0 + j + 1];
+            const uint32_t sz = next - prev;
+            prev = next;
+            sum += sz > static_cast<uint32_t>(LS_MAX) ? sz : 0u;
+            medium += sz > static_cast<uint32_t>(PL_MAX) ? sz : 0u;
         }
     }
     sum = wave_sum(sum);
@@ -913,7 +938,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     DK_HIP(ctx, hipMemsetAsync(d_hist, 0, 256 * sizeof(uint32_t), st));
     {
         LaunchScope ls(ctx, K_SYM_HIST, 1.0 * n);
-        const size_t blocks = std::min<size_t>(div_up(n, 256 * 16), 2048);
+        const size_t blocks = std::min<size_t>(div_up(n, 256 * 64), 2048);
         k_sym_hist<<<dim3(blocks), dim3(256), 0, st>>>(d_text, n, d_hist);
     }
     DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 16, d_hist, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -1062,7 +1087,9 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
         if (tsym > 0) {
             if (raw_text) tsym = 8;
             kbits = tsym * tbits;
-            const int tsym_big = std::min(tsym, (63 - bsbits) / tbits);
+            // the big list's key: (offset in the big list) above the leading symbols of the secondary key -- at most 32 bits of it: every
+            // digit of a list this short costs three launches, and what four more bytes leave unresolved the next round takes
+            const int tsym_big = std::min(std::min(tsym, (63 - bsbits) / tbits), std::max(1, 32 / tbits));
             kb = tsym_big * tbits;
             if (advanced) *advanced = nbig > 0 ? tsym_big : tsym;
         } else {
