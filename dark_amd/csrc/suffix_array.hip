@@ -510,8 +510,8 @@ __global__ __launch_bounds__(256) void k_big_reduce(const uint32_t *__restrict__
     const size_t g0 = static_cast<size_t>(blockIdx.x) * BG_TILE + static_cast<size_t>(threadIdx.x) * BG_IPT;
     uint32_t sum = 0, medium = 0;
     if (g0 < groups) {
-#pragma unroll
         uint32_t prev = gstart[g0];
+#pragma unroll
         for (int j = 0; j < BG_IPT && g0 + j < groups; ++j) {
             const uint32_t next = gstart[g0 + j + 1];
             const uint32_t sz = next - prev;
