@@ -1,7 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun, from the repo root): rocprofv3 kernel-trace statistics and the two PMC passes of the bench
 # command for one workload; everything lands under gpurun_out/prof_<workload>/.  The PMC passes are separate runs with counters only
-# (no trace domains).    usage: tools/profile_round.sh WORKLOAD [STEPS] [WARMUP]
+# (no trace domains).  bench.py runs WARMUP + STEPS steps with HIP-event pairs and 3 more without: all of them are in the counters.
+# usage: tools/profile_round.sh WORKLOAD [STEPS] [WARMUP]
 set -e -o pipefail
 WL=${1:-enwik8_like_1e8}
 STEPS=${2:-2}
@@ -20,7 +21,7 @@ echo "$WL FETCH_SIZE pass done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_WRITE_SIZE -- python3 $ROOT/bench.py $ARGS > $OUT/pmc_write.log 2>&1
 echo "$WL WRITE_SIZE pass done"
 cd $ROOT
-python3 tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE --steps $((STEPS + WARM)) --workload $WL > $OUT/pmc_traffic.json
+python3 tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE --steps $((STEPS + WARM + 3)) --workload $WL > $OUT/pmc_traffic.json
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 # keep the merge small: the raw counter CSVs are large
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/stats
