@@ -62,6 +62,8 @@ SIGNATURES = {
     "dk_bitcoder_decode": (_i, [_vp, _sz, _vp, _sz, _vp]),
     "dk_stream_encode": (_i, [_i, _sz, _vp, _vp, _vp, _vp, _vp, _sz, C.c_uint32, _vp, _sz, _szp]),
     "dk_stream_decode": (_i, [_i, _vp, _sz, _sz, _vp, _u32p, C.POINTER(_i), _szp]),
+    "dk_raw_stream_encode": (_i, [_i, _vp, _sz, C.c_uint32, _vp, _sz, _szp]),
+    "dk_raw_stream_decode": (_i, [_i, _vp, _sz, _sz, _vp, _u32p, _szp]),
     "dk_set_profiling": (_i, [_vp, _i]),
     "dk_stats_reset": (_i, [_vp]),
     "dk_get_stats": (_i, [_vp, C.POINTER(Stats)]),

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 SO = os.path.join(HERE, "libdark_amd.so")
-SOURCES = ["abi.cpp", "context.cpp", "entropy.cpp", "radix_sort.hip", "suffix_array.hip", "bwt.hip", "dc.hip"]
+SOURCES = ["abi.cpp", "context.cpp", "entropy.cpp", "bbb.cpp", "radix_sort.hip", "suffix_array.hip", "bwt.hip", "dc.hip"]
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "--offload-arch=" + ARCH]

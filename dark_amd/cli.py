@@ -1,6 +1,6 @@
 """Command line front end with the reference's conventions (src/main.rs:34-116).
 
-    python -m dark_amd.cli [-m dark|exp|ybs|simple|raw|rawdc] FILE        -> ./FILE with its extension replaced by .dark
+    python -m dark_amd.cli [-m dark|exp|ybs|simple|bbb|raw|rawdc] FILE       -> ./FILE with its extension replaced by .dark
     python -m dark_amd.cli [-m MODEL] FILE.dark                           -> ./FILE.orig
 
 The default model is `exp`, as in src/main.rs:52.  Output names follow PathBuf::set_extension (src/main.rs:64-66,96-98):
@@ -31,6 +31,7 @@ EXTENSION = "dark"
 STATS = {}  # --stats: when the library and its context were ready (imports, workspace allocation done)
 FOOTER_MAGIC = b"DKIX"
 DUMP_MODELS = ("raw", "rawdc")
+RAW_CODING_MODELS = ("bbb",)  # block::raw with a coding RawModel (src/main.rs:73,104): block after block through dk_raw_block_encode
 
 
 def set_extension(name, ext):
@@ -86,6 +87,9 @@ def _write_block(ctx, model, block, out, first, force):
         with open("out-dc.raw", "wb" if first else "ab") as dump:
             dump.write(ctx.block_encode("rawdc", block))
         out.write(b"\0\0\0\0")
+    elif model in RAW_CODING_MODELS:
+        # block::raw::Encoder with model::bbb::Model (src/main.rs:104): every byte value can be carried, no 0xFF restriction
+        out.write(ctx.raw_block_encode(block, 1))
     else:
         _check_ff(block, force, "the block")
         out.write(ctx.block_encode(model, block))         # main.rs:104-113
@@ -215,7 +219,7 @@ def encode_file(path, model, block_size=0, device=0, gpus=1, force=False, host_t
     if not block_size or block_size >= total:
         return _encode_single(path, model, device, force, out_path)
     nblocks = -(-total // block_size)
-    if model in DUMP_MODELS:  # dump-only models: block after block through the host entry points
+    if model in DUMP_MODELS or model in RAW_CODING_MODELS:  # block after block through the host entry points
         from .context import Context
         with open(path, "rb") as f, Context(block_size, device) as ctx, open(out_path, "wb") as out:
             for b in range(nblocks):
@@ -344,7 +348,7 @@ def decode_file(path, model, device=0, gpus=1, host_threads=0, devices=None):
     out_path = output_name(path, "orig")                    # main.rs:64-66
     if model in DUMP_MODELS:
         raise SystemExit("model %s is dump-only: there is nothing to decode (src/model/raw.rs:39-43 panics)" % model)
-    footer = read_footer(path)
+    footer = read_footer(path) if model not in RAW_CODING_MODELS else None  # bbb archives carry no index: records are walked
     threads = host_threads or max(1, _host_threads() // max(1, gpus) - 1)
     if footer is None:
         # no index: the reference's single-block file (main.rs:70), or concatenated records walked by the bytes each decode consumed
@@ -361,7 +365,10 @@ def decode_file(path, model, device=0, gpus=1, host_threads=0, devices=None):
                     if ctx is not None:
                         ctx.close()
                     ctx = Context(n, device)
-                out.write(ctx.block_decode(model, blob[pos:], n))
+                if model in RAW_CODING_MODELS:
+                    out.write(ctx.raw_block_decode(blob[pos:], n, 1))   # block::raw::Decoder, main.rs:73
+                else:
+                    out.write(ctx.block_decode(model, blob[pos:], n))
                 pos += ctx.last_consumed()
             if ctx is not None:
                 ctx.close()
@@ -407,7 +414,7 @@ def _worker_decode(args):
 
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="dark_amd.cli", description="Dark compressor usage: [options] input_file[.dark]")
-    ap.add_argument("-m", "--model", default="exp", help="dark|exp|ybs|simple|raw|rawdc (default exp, like the reference; raw and rawdc are dump-only)")
+    ap.add_argument("-m", "--model", default="exp", help="dark|exp|ybs|simple|bbb|raw|rawdc (default exp, like the reference; raw and rawdc are dump-only; bbb: DESIGN.md section 7)")
     ap.add_argument("-b", "--block-size", type=int, default=0, help="cut the input into blocks of this many bytes (extension; streamed and batched)")
     ap.add_argument("-d", "--device", type=int, default=0)
     ap.add_argument("--gpus", type=int, default=1, help="block b -> GPU b mod G, one worker process per GPU (needs -b / an indexed archive)")

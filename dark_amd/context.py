@@ -154,6 +154,15 @@ class Context:
         assert ln.value == 4 and not out[:4].any()
         return dump[:dl.value].tobytes()
 
+    def raw_block_encode(self, data, raw_model=1):
+        """block::raw::Encoder with a coding RawModel (1 = bbb) -> coded stream"""
+        t = as_u8(data)
+        n = len(t)
+        out = np.empty(2 * n + 4096, dtype=np.uint8)
+        ln, dl = C.c_size_t(0), C.c_size_t(0)
+        self._ck(self._lib.dk_raw_block_encode(self._h, int(raw_model), _ptr(t), n, _ptr(out), len(out), C.byref(ln), None, 0, C.byref(dl)))
+        return out[:ln.value].tobytes()
+
     def raw_block_decode(self, stream, n, raw_model=0):
         s = as_u8(stream)
         out = np.empty(n, dtype=np.uint8)

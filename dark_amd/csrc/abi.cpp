@@ -617,18 +617,17 @@ int dk_block_decode(dk_ctx *ctx, int model_id, const uint8_t *in, size_t in_len,
     return DK_OK;
 }
 
-// block::raw::Encoder::encode (src/block/raw.rs:35-59) with the dump model Out: SA -> BWT on the GPU, origin + L into `dump`
+// block::raw::Encoder::encode (src/block/raw.rs:35-59): SA -> BWT on the GPU; origin + L then go through the RawModel -- the dump model
+// Out (into `dump`) or the bbb coding model (into `out`; host, bit-serial)
 int dk_raw_block_encode(dk_ctx *ctx, int raw_model, const uint8_t *in, size_t n, uint8_t *out, size_t out_cap, size_t *out_len, uint8_t *dump,
                         size_t dump_cap, size_t *dump_len) {
     DK_TRY(begin_call(ctx));
     ScopedCall sc(ctx);
     if (!in || !out || !out_len) return ctx->fail(DK_E_ARG, "null pointer");
-    if (raw_model == DK_RAWMODEL_BBB)
-        return ctx->fail(DK_E_MODEL, "the bbb model needs compress::entropy::ari::apm::Gate, which is not part of the reference tree");
-    if (raw_model != DK_RAWMODEL_OUT) return ctx->fail(DK_E_MODEL, "unknown raw model %d", raw_model);
-    if (!dump || !dump_len) return ctx->fail(DK_E_ARG, "the Out model needs a dump buffer");
+    if (raw_model != DK_RAWMODEL_OUT && raw_model != DK_RAWMODEL_BBB) return ctx->fail(DK_E_MODEL, "unknown raw model %d", raw_model);
+    if (raw_model == DK_RAWMODEL_OUT && (!dump || !dump_len)) return ctx->fail(DK_E_ARG, "the Out model needs a dump buffer");
     DK_TRY(check_n(ctx, n));
-    if (dump_cap < n + 4 || out_cap < 4) return ctx->fail(DK_E_CAPACITY, "dump needs n + 4 bytes, out 4 bytes");
+    if (raw_model == DK_RAWMODEL_OUT && (dump_cap < n + 4 || out_cap < 4)) return ctx->fail(DK_E_CAPACITY, "dump needs n + 4 bytes, out 4 bytes");
     Timer t;
     uint8_t *d_text = ctx->ws_alloc<uint8_t>(n);
     uint8_t *d_bwt = ctx->ws_alloc<uint8_t>(n);
@@ -637,25 +636,55 @@ int dk_raw_block_encode(dk_ctx *ctx, int raw_model, const uint8_t *in, size_t n,
     DK_HIP(ctx, hipMemcpyAsync(d_text, in, n, hipMemcpyHostToDevice, ctx->stream));
     uint32_t origin = 0;
     DK_TRY(bwt_forward_device(ctx, d_text, n, d_sa, d_bwt, &origin));
-    DK_HIP(ctx, hipMemcpyAsync(dump + 4, d_bwt, n, hipMemcpyDeviceToHost, ctx->stream));
-    DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 4; ++i) dump[i] = static_cast<uint8_t>(origin >> (24 - 8 * i));  // src/block/raw.rs:48-51
-    *dump_len = n + 4;
-    std::memset(out, 0, 4);  // ari::Encoder::finish of a coder nothing was coded with: low = 0, four bytes
-    *out_len = 4;
+    if (raw_model == DK_RAWMODEL_OUT) {
+        DK_HIP(ctx, hipMemcpyAsync(dump + 4, d_bwt, n, hipMemcpyDeviceToHost, ctx->stream));
+        DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < 4; ++i) dump[i] = static_cast<uint8_t>(origin >> (24 - 8 * i));  // src/block/raw.rs:48-51
+        *dump_len = n + 4;
+        std::memset(out, 0, 4);  // ari::Encoder::finish of a coder nothing was coded with: low = 0, four bytes
+        *out_len = 4;
+    } else {
+        DK_TRY(ctx->ensure_stage(n + 64));
+        uint8_t *h_bwt = reinterpret_cast<uint8_t *>(ctx->h_stage);
+        DK_HIP(ctx, hipMemcpyAsync(h_bwt, d_bwt, n, hipMemcpyDeviceToHost, ctx->stream));
+        DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        Timer te;
+        const int rc = raw_bbb_encode_stream(h_bwt, n, origin, out, out_cap, out_len);
+        ctx->stats.ms_entropy = te.ms();
+        if (rc == DK_E_CAPACITY) return ctx->fail(rc, "output buffer of %zu bytes is too small", out_cap);
+        if (rc) return ctx->fail(rc, "bbb coding failed (%d)", rc);
+        if (dump_len) *dump_len = 0;
+    }
     ctx->stats.ms_total = t.ms();
     return DK_OK;
 }
 
 int dk_raw_block_decode(dk_ctx *ctx, int raw_model, const uint8_t *in, size_t in_len, size_t n, uint8_t *out) {
     DK_TRY(begin_call(ctx));
+    ScopedCall sc(ctx);
     if (!in || !out) return ctx->fail(DK_E_ARG, "null pointer");
-    (void)in_len;
-    if (raw_model == DK_RAWMODEL_BBB)
-        return ctx->fail(DK_E_MODEL, "the bbb model needs compress::entropy::ari::apm::Gate, which is not part of the reference tree");
-    if (raw_model != DK_RAWMODEL_OUT) return ctx->fail(DK_E_MODEL, "unknown raw model %d", raw_model);
+    if (raw_model != DK_RAWMODEL_OUT && raw_model != DK_RAWMODEL_BBB) return ctx->fail(DK_E_MODEL, "unknown raw model %d", raw_model);
     DK_TRY(check_n(ctx, n));
-    std::memset(out, 0, n);  // Out::decode returns symbol 0 ("not supported", src/model/raw.rs:71-75): origin 0, a BWT of zeros -> n zeros
+    if (raw_model == DK_RAWMODEL_OUT) {
+        std::memset(out, 0, n);  // Out::decode returns symbol 0 ("not supported", src/model/raw.rs:71-75): origin 0, a BWT of zeros -> n zeros
+        return DK_OK;
+    }
+    Timer t;
+    DK_TRY(ctx->ensure_stage(n + 64));
+    uint8_t *h_bwt = reinterpret_cast<uint8_t *>(ctx->h_stage);
+    uint32_t origin = 0;
+    const int rc = raw_bbb_decode_stream(in, in_len, n, h_bwt, &origin, &ctx->last_consumed);
+    ctx->stats.ms_entropy = t.ms();
+    if (rc) return ctx->fail(rc, "bbb stream does not decode");
+    if (origin >= n) return ctx->fail(DK_E_STREAM, "decoded origin %u is outside the block", origin);
+    uint8_t *d_bwt = ctx->ws_alloc<uint8_t>(n);
+    uint8_t *d_out = ctx->ws_alloc<uint8_t>(n);
+    if (!d_bwt || !d_out) return DK_E_NOMEM;
+    DK_HIP(ctx, hipMemcpyAsync(d_bwt, h_bwt, n, hipMemcpyHostToDevice, ctx->stream));
+    DK_TRY(bwt_inverse_device(ctx, d_bwt, n, origin, d_out));
+    DK_HIP(ctx, hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, ctx->stream));
+    DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats.ms_total = t.ms();
     return DK_OK;
 }
 
@@ -786,6 +815,17 @@ int dk_stream_decode(int model_id, const uint8_t *in, size_t in_len, size_t n, u
     int rc = decode_block_stream(model_id, in, in_len, n, bwt_out, origin, &single, consumed);
     if (single_symbol) *single_symbol = single;
     return rc;
+}
+
+int dk_raw_stream_encode(int raw_model, const uint8_t *bwt, size_t n, uint32_t origin, uint8_t *out, size_t out_cap, size_t *out_len) {
+    if (!bwt || !out || !out_len || n == 0) return DK_E_ARG;
+    if (raw_model != DK_RAWMODEL_BBB) return DK_E_MODEL;
+    return raw_bbb_encode_stream(bwt, n, origin, out, out_cap, out_len);
+}
+int dk_raw_stream_decode(int raw_model, const uint8_t *in, size_t in_len, size_t n, uint8_t *bwt_out, uint32_t *origin, size_t *consumed) {
+    if (!in || !bwt_out || !origin || n == 0) return DK_E_ARG;
+    if (raw_model != DK_RAWMODEL_BBB) return DK_E_MODEL;
+    return raw_bbb_decode_stream(in, in_len, n, bwt_out, origin, consumed);
 }
 
 // ---- measurement ----------------------------------------------------------------------------------------------------------

@@ -492,6 +492,9 @@ int model_decode_stream(int model_id, const uint8_t *in, size_t in_len, const ui
 // src/entropy/{mod,ari}.rs
 int bitcoder_encode(const uint8_t *bits, const uint16_t *flat, size_t nbits, uint8_t *out, size_t cap, size_t *out_len);
 int bitcoder_decode(const uint8_t *in, size_t in_len, const uint16_t *flat, size_t nbits, uint8_t *bits);
+// block::raw with the bbb model (src/block/raw.rs, src/model/bbb.rs; bbb.cpp -- gates restated after etc/bbb/main.cpp, PARITY UNPINNED)
+int raw_bbb_encode_stream(const uint8_t *bwt, size_t n, uint32_t origin, uint8_t *out, size_t cap, size_t *out_len);
+int raw_bbb_decode_stream(const uint8_t *in, size_t in_len, size_t n, uint8_t *bwt, uint32_t *origin, size_t *consumed = nullptr);
 // largest n a model can code without losing bits (0 = unknown model)
 uint64_t model_max_block(int model_id);
 

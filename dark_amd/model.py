@@ -68,3 +68,28 @@ def stream_decode(model, stream, n, with_consumed=False):
     if with_consumed:
         return out, int(origin.value), bool(single.value), int(used.value)
     return out, int(origin.value), bool(single.value)
+
+
+def raw_stream_encode(bwt, origin, raw_model=1):
+    """host half of block::raw with a coding RawModel (1 = bbb): src/block/raw.rs:45-58 from (L, origin) to the coded stream"""
+    lib = _lib.load()
+    b = as_u8(bwt)
+    out = np.empty(2 * len(b) + 4096, dtype=np.uint8)
+    ln = C.c_size_t(0)
+    rc = lib.dk_raw_stream_encode(int(raw_model), _ptr(b), len(b), int(origin), _ptr(out), len(out), C.byref(ln))
+    if rc:
+        raise DarkError(rc)
+    return out[:ln.value].tobytes()
+
+
+def raw_stream_decode(stream, n, raw_model=1):
+    """-> (bwt, origin, bytes consumed)"""
+    lib = _lib.load()
+    s = as_u8(stream)
+    out = np.empty(n, dtype=np.uint8)
+    origin = C.c_uint32(0)
+    used = C.c_size_t(0)
+    rc = lib.dk_raw_stream_decode(int(raw_model), _ptr(s), len(s), n, _ptr(out), C.byref(origin), C.byref(used))
+    if rc:
+        raise DarkError(rc)
+    return out, int(origin.value), int(used.value)

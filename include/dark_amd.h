@@ -84,8 +84,10 @@ int dk_block_decode(dk_ctx *ctx, int model_id, const uint8_t *in, size_t in_len,
  *   DK_RAWMODEL_OUT  model::raw::Out src/model/raw.rs:46-76: every symbol is appended to ./out.raw, nothing reaches the coder.  Here the
  *                    symbols come back in `dump` (n + 4 bytes) and `out` receives what the idle coder's finish() writes (4 zero bytes).
  *                    Decoding "is not supported" in the reference (raw.rs:71-75 returns symbol 0 for everything): n zero bytes, DK_OK.
- *   DK_RAWMODEL_BBB  model::bbb::Model src/model/bbb.rs: not built -- its gates are compress::entropy::ari::apm::Gate, whose arithmetic
- *                    is in the un-vendored crate and appears nowhere in the reference tree; DK_E_MODEL. */
+ *   DK_RAWMODEL_BBB  model::bbb::Model src/model/bbb.rs: the BWT bytes are coded bit by bit into `out` (dump is not used, may be NULL).
+ *                    The model's structure follows bbb.rs; its gates (compress::entropy::ari::apm::Gate, not in the reference tree)
+ *                    are restated after the in-repo analogue etc/bbb/main.cpp:348-460 -- PARITY UNPINNED: a stream made here decodes
+ *                    here; compatibility with the Rust crate's bytes is not claimed. */
 #define DK_RAWMODEL_OUT 0
 #define DK_RAWMODEL_BBB 1
 int dk_raw_block_encode(dk_ctx *ctx, int raw_model, const uint8_t *in, size_t n, uint8_t *out, size_t out_cap, size_t *out_len,
@@ -166,6 +168,11 @@ int dk_stream_encode(int model_id, size_t n, const uint32_t init[256], const uin
                      uint8_t *out, size_t out_cap, size_t *out_len);
 int dk_stream_decode(int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *bwt_out, uint32_t *origin,
                      int *single_symbol, size_t *consumed /* may be NULL: bytes of `in` read = the length the encoder wrote */);
+
+/* Host half of block::raw on its own (what the GPU BWT feeds / is fed by): src/block/raw.rs:45-58 from (L, origin) to the coded stream and
+ * src/block/raw.rs:85-97 back.  raw_model must be a coding model (DK_RAWMODEL_BBB). */
+int dk_raw_stream_encode(int raw_model, const uint8_t *bwt, size_t n, uint32_t origin, uint8_t *out, size_t out_cap, size_t *out_len);
+int dk_raw_stream_decode(int raw_model, const uint8_t *in, size_t in_len, size_t n, uint8_t *bwt_out, uint32_t *origin, size_t *consumed);
 
 /* ---- measurement ------------------------------------------------------------------------------------------ */
 #define DK_NUM_KERNEL_SLOTS 32

@@ -1120,3 +1120,204 @@ int orc_bitcoder_decode(const uint8_t *in, size_t in_len, const uint16_t *flat, 
     }
     return 0;
 }
+
+/* ================================================================================================
+ * `bbb` coding model (src/model/bbb.rs) over block::raw (src/block/raw.rs:35-104)
+ *
+ * PARITY UNPINNED, and more weakly anchored than anything above.  bbb.rs itself is in the reference and is
+ * followed line by line (state map, contexts, the five gate stages, their mixing, the update order).  But every
+ * gate is compress::entropy::ari::apm::Gate and every probability an apm::Bit, whose arithmetic lives in the
+ * un-vendored crate.  They are restated after the model's in-repo ANALOGUE, Mahoney's bbb
+ * (etc/bbb/main.cpp: squash :348-359, Stretch :361-382, class APM :425-460), under these assumptions:
+ *   G1  Bit = 12-bit probability of a ZERO bit (as for the exp model above; src/entropy/ari.rs:22-30 relies on it);
+ *       a true bit is coded in [flat, 4096), a false one in [0, flat)
+ *   G2  Bit::to_wide / from_wide = Mahoney's stretch / squash (d scaled by 8 bits, 33-point table)
+ *   G3  Gate = 33 bins of 16-bit probabilities, initialised to squash((j-16)*128)*16, pass = linear interpolation
+ *       between the two bins around stretch(p), BinCoords = (bin, weight)
+ *   G4  Gate::update(bit, coords, rate, 0) moves BOTH bins towards the observed bit with shift rate+4: bbb.rs passes
+ *       1,5,3,4,3,3 where main.cpp:502-507 passes 5,9,7,8,7,7 to the same six stages
+ *   G5  Bit::predict() is "flat >= 2048" (bbb.rs:268-274 then mirrors main.cpp:542 `p+=p<2048`)
+ * None of G2-G5 can be checked in this image; a stream made here round-trips here and nowhere else is claimed.
+ * ============================================================================================== */
+static const uint8_t BBB_STATE_FLAT[256 * 4] = {
+#include "../dark_amd/csrc/bbb_states.inc"
+};
+#define BBB_STATE(state, col) BBB_STATE_FLAT[(state) * 4 + (col)]
+
+static int bbb_squash(int d) { /* etc/bbb/main.cpp:348-359 */
+    static const int t[33] = {1, 2, 3, 6, 10, 16, 27, 45, 73, 120, 194, 310, 488, 747, 1101, 1546, 2047, 2549, 2994, 3348, 3607, 3785, 3901,
+                              3975, 4022, 4050, 4068, 4079, 4085, 4089, 4092, 4093, 4094};
+    if (d > 2047) return 4095;
+    if (d < -2047) return 0;
+    int w = d & 127;
+    d = (d >> 7) + 16;
+    return (t[d] * (128 - w) + t[d + 1] * w + 64) >> 7;
+}
+static short g_bbb_stretch[4096];
+static int g_bbb_stretch_ready;
+static void bbb_stretch_init(void) { /* etc/bbb/main.cpp:373-382 */
+    if (g_bbb_stretch_ready) return;
+    int pi = 0;
+    for (int x = -2047; x <= 2047; ++x) {
+        int i = bbb_squash(x);
+        for (int j = pi; j <= i; ++j) g_bbb_stretch[j] = (short)x;
+        pi = i + 1;
+    }
+    g_bbb_stretch[4095] = 2047;
+    g_bbb_stretch_ready = 1;
+}
+
+typedef struct { uint16_t t[33]; } BbbGate;            /* [compress] apm::Gate (G3) */
+typedef struct { int bin, weight; } BbbCoords;          /* [compress] apm::BinCoords */
+static void bbbgate_new(BbbGate *g) { for (int j = 0; j < 33; ++j) g->t[j] = (uint16_t)(bbb_squash((j - 16) * 128) * 16); }
+static uint32_t bbbgate_pass(const BbbGate *g, uint32_t flat, BbbCoords *bc) { /* main.cpp:442-450 */
+    int s = g_bbb_stretch[flat];
+    bc->weight = s & 127;
+    bc->bin = (s + 2048) >> 7;
+    return (uint32_t)((g->t[bc->bin] * (128 - bc->weight) + g->t[bc->bin + 1] * bc->weight) >> 11);
+}
+static void bbbgate_update(BbbGate *g, int bit, BbbCoords bc, int rate) { /* main.cpp:444-446, G4 */
+    int r = rate + 4, z = bit ? 0 : 1;
+    int target = (z << 16) + (z << r) - z - z;
+    g->t[bc.bin] = (uint16_t)(g->t[bc.bin] + ((target - (int)g->t[bc.bin]) >> r));
+    g->t[bc.bin + 1] = (uint16_t)(g->t[bc.bin + 1] + ((target - (int)g->t[bc.bin + 1]) >> r));
+}
+
+typedef struct { /* bbb.rs:150-173 */
+    size_t ctx_id;
+    uint8_t ctx2state[256];
+    uint16_t sm_table[256];
+    uint8_t bit_context;
+    uint32_t last_bytes;
+    uint16_t run_count, run_context;
+    BbbGate gate1a[0x100], gate1b[0x100], gate2[0x10000], gate3[0x400], gate4[0x2000], gate5[0x4000];
+} BbbModel;
+typedef struct { BbbCoords b11, b12, b2, b3, b4, b5; size_t c1, c2, c3, c4, c5; } BbbCookie; /* bbb.rs:175-187 */
+
+static void bbb_reset(BbbModel *m) { /* bbb.rs:191-205 via reset() :284-286, StateMap::new :108-126 */
+    bbb_stretch_init();
+    m->ctx_id = 0;
+    memset(m->ctx2state, 0, sizeof m->ctx2state);
+    for (int i = 0; i < 256; ++i) {
+        size_t n0 = BBB_STATE(i, 2), n1 = BBB_STATE(i, 3);
+        if (n0 == 0) n1 <<= 7;
+        if (n1 == 0) n0 <<= 7;
+        m->sm_table[i] = (uint16_t)(((n0 + 1) << 16) / (n0 + n1 + 2));
+    }
+    m->bit_context = 1;
+    m->last_bytes = 0;
+    m->run_count = 0;
+    m->run_context = 0;
+    BbbGate proto;
+    bbbgate_new(&proto);
+    for (size_t i = 0; i < 0x100; ++i) { m->gate1a[i] = proto; m->gate1b[i] = proto; }
+    for (size_t i = 0; i < 0x10000; ++i) m->gate2[i] = proto;
+    for (size_t i = 0; i < 0x400; ++i) m->gate3[i] = proto;
+    for (size_t i = 0; i < 0x2000; ++i) m->gate4[i] = proto;
+    for (size_t i = 0; i < 0x4000; ++i) m->gate5[i] = proto;
+}
+static uint32_t bbb_predict(const BbbModel *m, BbbCookie *ck) { /* bbb.rs:232-280 */
+    uint32_t p0 = (uint32_t)(m->sm_table[m->ctx2state[m->ctx_id]] >> (16 - FLAT_BITS)); /* StateMap::predict :139-143 */
+    size_t bit_context = m->bit_context, last_bytes = m->last_bytes;
+    ck->c1 = bit_context;
+    uint32_t p11 = bbbgate_pass(&m->gate1a[ck->c1], p0, &ck->b11);
+    uint32_t p12 = bbbgate_pass(&m->gate1b[ck->c1], p0, &ck->b12);
+    uint32_t p1 = (p11 + p12 + 1) >> 1;
+    ck->c2 = bit_context | ((last_bytes & 0xFF) << 8);
+    uint32_t p2 = bbbgate_pass(&m->gate2[ck->c2], p1, &ck->b2);
+    ck->c3 = (last_bytes & 0xFF) | (size_t)m->run_context;
+    uint32_t p3 = bbbgate_pass(&m->gate3[ck->c3], p2, &ck->b3);
+    ck->c4 = bit_context | (last_bytes & 0x1F00);
+    uint32_t p4x = bbbgate_pass(&m->gate4[ck->c4], p3, &ck->b4);
+    uint32_t p4 = (p4x * 3 + p3 + 2) >> 2;
+    size_t c5y = bit_context ^ (last_bytes & 0xFFFFFF);
+    ck->c5 = ((c5y * 123456791u) & 0xFFFFFFFFu) >> 18;
+    uint32_t p5x = bbbgate_pass(&m->gate5[ck->c5], p4, &ck->b5);
+    uint32_t p5 = (p5x + p4 + 1) >> 1;
+    return p5 >= (FLAT_TOTAL >> 1) ? p5 : p5 + 1; /* :268-274, G5 */
+}
+static void bbb_update(BbbModel *m, int bit, int reset, const BbbCookie *ck) { /* bbb.rs:197-230 */
+    m->bit_context = (uint8_t)(((m->bit_context & 0x7F) << 1) | bit);
+    if (reset) {
+        m->last_bytes = ((m->last_bytes & 0xFFFFFF) << 8) | m->bit_context;
+        m->bit_context = 1;
+        if (((m->last_bytes ^ (m->last_bytes >> 8)) & 0xFF) == 0) {
+            if (m->run_count < 0xFFFF) m->run_count += 1;
+            if (m->run_count == 1 || m->run_count == 2 || m->run_count == 4) m->run_context += 0x100;
+        } else {
+            m->run_count = 0;
+            m->run_context = 0;
+        }
+    }
+    { /* StateMap::update :128-137 */
+        size_t state = m->ctx2state[m->ctx_id];
+        m->ctx2state[m->ctx_id] = BBB_STATE(state, bit);
+        size_t top = (size_t)(1 - bit) << 16, old = m->sm_table[state];
+        m->sm_table[state] = (uint16_t)((0xFF * old + top + 0x80) >> 8);
+    }
+    m->ctx_id = m->bit_context;
+    bbbgate_update(&m->gate1a[ck->c1], bit, ck->b11, 1);
+    bbbgate_update(&m->gate1b[ck->c1], bit, ck->b12, 5);
+    bbbgate_update(&m->gate2[ck->c2], bit, ck->b2, 3);
+    bbbgate_update(&m->gate3[ck->c3], bit, ck->b3, 4);
+    bbbgate_update(&m->gate4[ck->c4], bit, ck->b4, 3);
+    bbbgate_update(&m->gate5[ck->c5], bit, ck->b5, 3);
+}
+static int bbb_encode_sym(BbbModel *m, uint8_t sym, Enc *e) { /* bbb.rs:288-297 */
+    for (int i = 7; i >= 0; --i) {
+        int bit = (sym >> i) & 1;
+        BbbCookie ck;
+        uint32_t flat = bbb_predict(m, &ck);
+        if (binraw_encode(e, flat, FLAT_TOTAL, bit)) return -1;
+        bbb_update(m, bit, i == 0, &ck);
+    }
+    return 0;
+}
+static int bbb_decode_sym(BbbModel *m, Dec *d, uint8_t *sym) { /* bbb.rs:299-310 */
+    uint8_t s = 0;
+    for (int i = 7; i >= 0; --i) {
+        BbbCookie ck;
+        uint32_t flat = bbb_predict(m, &ck);
+        int bit;
+        if (binraw_decode(d, flat, FLAT_TOTAL, &bit)) return -1;
+        s |= (uint8_t)(bit << i);
+        bbb_update(m, bit, i == 0, &ck);
+    }
+    *sym = s;
+    return 0;
+}
+
+/* block::raw::Encoder::encode (src/block/raw.rs:35-59) with the bbb model, from a given BWT + origin */
+int orc_raw_bbb_encode_bwt(const uint8_t *bwt, size_t n, uint32_t origin, uint8_t *out, size_t cap, size_t *out_len) {
+    BbbModel *m = (BbbModel *)malloc(sizeof *m);
+    if (!m) return -2;
+    bbb_reset(m);
+    Enc eh;
+    enc_new(&eh, out, cap);
+    int rc = 0;
+    rc = rc || bbb_encode_sym(m, (uint8_t)(origin >> 24), &eh);
+    rc = rc || bbb_encode_sym(m, (uint8_t)(origin >> 16), &eh);
+    rc = rc || bbb_encode_sym(m, (uint8_t)(origin >> 8), &eh);
+    rc = rc || bbb_encode_sym(m, (uint8_t)origin, &eh);
+    for (size_t i = 0; i < n && !rc; ++i) rc = bbb_encode_sym(m, bwt[i], &eh);
+    if (!rc) rc = enc_finish(&eh);
+    free(m);
+    if (rc || eh.err) return eh.err ? eh.err : -1;
+    *out_len = eh.len;
+    return 0;
+}
+/* block::raw::Decoder::decode (src/block/raw.rs:84-104) up to the BWT + origin */
+int orc_raw_bbb_decode_bwt(const uint8_t *in, size_t in_len, size_t n, uint8_t *bwt, uint32_t *origin) {
+    BbbModel *m = (BbbModel *)malloc(sizeof *m);
+    if (!m) return -2;
+    bbb_reset(m);
+    Dec dh;
+    dec_new(&dh, in, in_len);
+    uint8_t b[4];
+    int rc = 0;
+    for (int k = 0; k < 4 && !rc; ++k) rc = bbb_decode_sym(m, &dh, &b[k]);
+    *origin = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
+    for (size_t i = 0; i < n && !rc; ++i) rc = bbb_decode_sym(m, &dh, &bwt[i]);
+    free(m);
+    return (rc || dh.err) ? -5 : 0;
+}

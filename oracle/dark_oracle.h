@@ -61,6 +61,11 @@ int orc_model_decode(int model_id, const uint8_t *in, size_t in_len, const uint8
 int orc_bitcoder_encode(const uint8_t *bits, const uint16_t *flat, size_t nbits, uint8_t *out, size_t cap, size_t *out_len);
 int orc_bitcoder_decode(const uint8_t *in, size_t in_len, const uint16_t *flat, size_t nbits, uint8_t *bits);
 
+/* block::raw::{Encoder,Decoder} with model::bbb::Model (src/block/raw.rs:35-104, src/model/bbb.rs), entered after / left before the
+ * BWT.  The gates of the model are restated after etc/bbb/main.cpp (assumptions G1-G5 in dark_oracle.c): PARITY UNPINNED. */
+int orc_raw_bbb_encode_bwt(const uint8_t *bwt, size_t n, uint32_t origin, uint8_t *out, size_t cap, size_t *out_len);
+int orc_raw_bbb_decode_bwt(const uint8_t *in, size_t in_len, size_t n, uint8_t *bwt, uint32_t *origin);
+
 /* stage timers of the last orc_block_dc_encode call on this thread (seconds): sa, bwt, dc, entropy */
 void orc_last_stage_seconds(double out[4]);
 

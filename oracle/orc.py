@@ -18,7 +18,7 @@ MODEL_IDS = {"dark": 0, "exp": 1, "ybs": 2, "simple": 3, "rawdc": 4}
 
 def build(force=False):
     """Compile the oracle with gcc (plain C, no GPU)."""
-    srcs = [os.path.join(_HERE, f) for f in ("dark_oracle.c", "dark_oracle.h", "sais_body.inc")]
+    srcs = [os.path.join(_HERE, f) for f in ("dark_oracle.c", "dark_oracle.h", "sais_body.inc", "../dark_amd/csrc/bbb_states.inc")]
     if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs):
         return _SO
     subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -49,6 +49,8 @@ def lib():
         L.orc_model_decode.argtypes = [C.c_int, u8p, C.c_size_t, u8p, C.c_size_t, u32p]
         L.orc_bitcoder_encode.argtypes = [u8p, u16p, C.c_size_t, u8p, C.c_size_t, szp]
         L.orc_bitcoder_decode.argtypes = [u8p, C.c_size_t, u16p, C.c_size_t, u8p]
+        L.orc_raw_bbb_encode_bwt.argtypes = [u8p, C.c_size_t, C.c_uint32, u8p, C.c_size_t, szp]
+        L.orc_raw_bbb_decode_bwt.argtypes = [u8p, C.c_size_t, C.c_size_t, u8p, C.POINTER(C.c_uint32)]
         L.orc_last_stage_seconds.argtypes = [C.POINTER(C.c_double * 4)]
         L.orc_last_stage_seconds.restype = None
         _lib = L
@@ -199,6 +201,26 @@ def bitcoder_decode(stream, flat):
     bits = np.empty(len(flat), dtype=np.uint8)
     _ck(lib().orc_bitcoder_decode(_p(s), len(s), _p(flat), len(flat), _p(bits)), "orc_bitcoder_decode")
     return bits
+
+
+def raw_bbb_encode(data_or_bwt, origin=None):
+    """block::raw::Encoder with the bbb model: from the text (origin None) or from a given BWT + origin"""
+    x = _u8(data_or_bwt)
+    if origin is None:
+        x, origin = bwt_forward(x)
+    n = len(x)
+    out = np.empty(2 * n + 4096, dtype=np.uint8)
+    ln = C.c_size_t(0)
+    _ck(lib().orc_raw_bbb_encode_bwt(_p(x), n, origin, _p(out), len(out), C.byref(ln)), "orc_raw_bbb_encode_bwt")
+    return out[:ln.value].tobytes()
+
+
+def raw_bbb_decode(stream, n):
+    s = _u8(stream)
+    bwt = np.empty(n, dtype=np.uint8)
+    origin = C.c_uint32(0)
+    _ck(lib().orc_raw_bbb_decode_bwt(_p(s), len(s), n, _p(bwt), C.byref(origin)), "orc_raw_bbb_decode_bwt")
+    return bwt_inverse(bwt, int(origin.value)).tobytes()
 
 
 def last_stage_seconds():

@@ -210,3 +210,25 @@ def test_cli_names_follow_set_extension():
         assert cli.output_name(name, "dark") == want, name
     assert cli.output_name("book.dark", "orig") == "book.orig"
     assert cli.has_extension("x/book.dark", "dark") and not cli.has_extension(".dark", "dark") and not cli.has_extension("dark", "dark")
+
+
+def test_bbb_raw_stream_matches_oracle(orc, license_bytes):
+    """block::raw with the bbb model (src/block/raw.rs:45-58,85-97, src/model/bbb.rs): product coder == oracle restatement, byte for
+    byte, and both round-trip.  PARITY UNPINNED: both build the gates after etc/bbb/main.cpp (assumptions G1-G5 in oracle/dark_oracle.c)."""
+    rng = np.random.default_rng(37)
+    cases = [np.frombuffer(license_bytes, np.uint8), np.zeros(300, np.uint8), np.frombuffer(b"abracadabra" * 30, np.uint8),
+             rng.integers(0, 256, size=5000, dtype=np.uint8), rng.integers(0, 4, size=20000, dtype=np.uint8),
+             np.repeat(rng.integers(0, 50, size=400, dtype=np.uint8), rng.integers(1, 40, size=400)), np.array([7, 7], np.uint8)]
+    for t in cases:
+        t = np.ascontiguousarray(t)
+        bwt, origin = orc.bwt_forward(t)
+        s = model.raw_stream_encode(bwt, origin)
+        assert s == orc.raw_bbb_encode(bwt, origin), len(t)
+        b2, o2, used = model.raw_stream_decode(s + b"\x11" * 5, len(t))
+        assert (b2 == bwt).all() and o2 == origin and used == len(s)
+        assert orc.raw_bbb_decode(s, len(t)) == t.tobytes()
+    with pytest.raises(dark_amd.DarkError):
+        model.raw_stream_decode(b"\x00\x01", 50)
+    with pytest.raises(dark_amd.DarkError) as e:
+        model.raw_stream_encode(b"abc", 0, raw_model=0)  # the dump model codes nothing: not a stream model
+    assert e.value.code == _lib.DK_E_MODEL

@@ -219,6 +219,12 @@ def test_cli_container(tmp_path, orc, license_bytes, monkeypatch):
     cli.main(["-m", "exp", str(src)])
     cli.main(["-m", "exp", "book.dark"])
     assert open("book.orig", "rb").read() == data
+    # -m bbb: block::raw with the coding model (src/main.rs:73,104); single block and walked multi-record form
+    out = cli.encode_file(str(src), "bbb")
+    assert open(out, "rb").read() == struct.pack("<I", len(data)) + orc.raw_bbb_encode(data)
+    assert open(cli.decode_file(out, "bbb"), "rb").read() == data
+    out = cli.encode_file(str(src), "bbb", 12345)
+    assert open(cli.decode_file(out, "bbb"), "rb").read() == data
     # dump models (src/model/raw.rs): out.raw = origin (4 bytes, big-endian order) + BWT; out-dc.raw = 10-byte records
     cli.encode_file(str(src), "raw", 0, 0)
     bwt, origin = orc.bwt_forward(data)
@@ -260,8 +266,17 @@ def test_raw_block_codec(ctx, orc, license_bytes):
     assert dump == struct.pack(">I", origin) + bwt.tobytes()
     assert ctx.raw_block_decode(b"\0\0\0\0", 10) == b"\0" * 10  # Out::decode "not supported": symbol 0 for everything
     with pytest.raises(dark_amd.DarkError) as e:
-        ctx.raw_block_encode_dump(license_bytes, raw_model=1)     # bbb: compress::...::apm::Gate is not in the reference tree
+        ctx.raw_block_encode_dump(license_bytes, raw_model=7)
     assert e.value.code == dark_amd._lib.DK_E_MODEL
+    # the coding RawModel bbb (src/model/bbb.rs; gates after etc/bbb/main.cpp, PARITY UNPINNED): GPU BWT + host coder == oracle, round trip
+    rng = np.random.default_rng(73)
+    for t in (np.frombuffer(license_bytes * 5, np.uint8), rng.integers(0, 256, size=30000, dtype=np.uint8), np.zeros(5000, np.uint8),
+              text_like(rng, 200000)):
+        t = np.ascontiguousarray(t)
+        s = ctx.raw_block_encode(t, 1)
+        assert s == orc.raw_bbb_encode(t), len(t)
+        assert ctx.raw_block_decode(s, len(t), 1) == t.tobytes()   # bytes 0xFF included: block::raw has no header quirk
+        assert ctx.last_consumed() == len(s)
     lib = dark_amd.load_library()
     assert ctx.last_block_flags() == 0
     ctx.block_encode("dark", b"abc\xffdef")
