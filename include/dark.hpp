@@ -4,7 +4,8 @@
 //   dark::saca::Constructor            src/saca.rs:344-384   new(max_n) / capacity() / compute(input)
 //   dark::block::dc::Encoder<Model>    src/block/dc.rs:21-92  new(n, model) / encode(input, writer) -> (writer, result)
 //   dark::block::dc::Decoder<Model>    src/block/dc.rs:96-161 new(n, model) / decode(reader, writer) -> (reader, writer, result)
-//   dark::model::{dark,exp,ybs,simple}::Model   src/model/*.rs  (the state lives in the library; the type selects it)
+//   dark::block::raw::Encoder<Model> / Decoder<Model>   src/block/raw.rs:17-105 (Model = model::bbb::Model or model::raw::Out)
+//   dark::model::{dark,exp,ybs,simple,bbb}::Model, dark::model::raw::Out   src/model/*.rs  (the state lives in the library; the type selects it)
 // Where the Rust code panics (assert!/unwrap) this throws dark::Error; io::Result becomes dark::Result{ok, message}.
 #pragma once
 #include <cstdint>
@@ -43,6 +44,8 @@ namespace dark { struct Model { static constexpr int ID = DK_MODEL_DARK; void re
 namespace exp { struct Model { static constexpr int ID = DK_MODEL_EXP; void reset() {} }; }
 namespace ybs { struct Model { static constexpr int ID = DK_MODEL_YBS; void reset() {} }; }
 namespace simple { struct Model { static constexpr int ID = DK_MODEL_SIMPLE; void reset() {} }; }
+namespace bbb { struct Model { static constexpr int RAW_ID = DK_RAWMODEL_BBB; void reset() {} }; }   // src/model/bbb.rs
+namespace raw { struct Out { static constexpr int RAW_ID = DK_RAWMODEL_OUT; std::vector<uint8_t> dumped; void reset() {} }; }  // src/model/raw.rs:46-76: "out.raw"
 }  // namespace model
 
 namespace saca {
@@ -108,6 +111,47 @@ private:
     size_t n_;
 };
 }  // namespace dc
+
+namespace raw {  // src/block/raw.rs
+template <class M>
+class Encoder {
+public:
+    M model;
+    Encoder(size_t n, M m, int device = 0) : model(m), ctx_(n, device) { model.reset(); }
+    template <class W>
+    std::pair<W, Result> encode(const std::vector<uint8_t> &input, W writer) {
+        if (input.size() > dk_capacity(ctx_.get())) throw Error(DK_E_ARG, "assertion failed: block_size <= self.sac.capacity()");
+        std::vector<uint8_t> out(2 * input.size() + 4096), dump(input.size() + 4);
+        size_t len = 0, dumped = 0;
+        int rc = dk_raw_block_encode(ctx_.get(), M::RAW_ID, input.data(), input.size(), out.data(), out.size(), &len, dump.data(), dump.size(), &dumped);
+        if (rc != DK_OK) return {std::move(writer), Result{false, ctx_.error()}};
+        keep_dump(model, dump, dumped);
+        writer.insert(writer.end(), out.begin(), out.begin() + static_cast<std::ptrdiff_t>(len));
+        return {std::move(writer), Result{}};
+    }
+private:
+    static void keep_dump(model::raw::Out &m, const std::vector<uint8_t> &d, size_t k) { m.dumped.assign(d.begin(), d.begin() + static_cast<std::ptrdiff_t>(k)); }
+    template <class Other> static void keep_dump(Other &, const std::vector<uint8_t> &, size_t) {}
+    detail::Ctx ctx_;
+};
+template <class M>
+class Decoder {
+public:
+    M model;
+    Decoder(size_t n, M m, int device = 0) : model(m), ctx_(n, device), n_(n) { model.reset(); }
+    template <class W>
+    std::tuple<std::vector<uint8_t>, W, Result> decode(std::vector<uint8_t> reader, W writer) {
+        std::vector<uint8_t> out(n_);
+        int rc = dk_raw_block_decode(ctx_.get(), M::RAW_ID, reader.data(), reader.size(), n_, out.data());
+        if (rc != DK_OK) return {std::move(reader), std::move(writer), Result{false, ctx_.error()}};
+        writer.insert(writer.end(), out.begin(), out.end());
+        return {std::move(reader), std::move(writer), Result{}};
+    }
+private:
+    detail::Ctx ctx_;
+    size_t n_;
+};
+}  // namespace raw
 }  // namespace block
 
 namespace bwt {  // the pieces of crate `compress` the reference's tests call next to saca (src/saca.rs:398-405)

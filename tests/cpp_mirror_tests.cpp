@@ -62,6 +62,23 @@ int main(int argc, char **argv) {
     if (roundtrip(dark::model::ybs::Model(), text)) return 1;
     if (roundtrip(dark::model::dark::Model(), text)) return 1;
     if (roundtrip(dark::model::simple::Model(), text)) return 1;
+    // block::raw with the coding model bbb (src/block/raw.rs:35-104; the reference has no unit test for it, its Makefile packs with -m bbb)
+    {
+        dark::block::raw::Encoder<dark::model::bbb::Model> enc(text.size(), dark::model::bbb::Model());
+        auto [writer, err] = enc.encode(text, Bytes());
+        err.unwrap();
+        dark::block::raw::Decoder<dark::model::bbb::Model> dec(text.size(), enc.model);
+        auto [reader, output, err2] = dec.decode(writer, Bytes());
+        (void)reader;
+        err2.unwrap();
+        CHECK(output == text);
+        CHECK(writer.size() < text.size());
+        // the dump model: origin (4 bytes) + L land in the model, the coder writes its 4-byte tail only
+        dark::block::raw::Encoder<dark::model::raw::Out> dump(text.size(), dark::model::raw::Out());
+        auto [w2, e2] = dump.encode(text, Bytes());
+        e2.unwrap();
+        CHECK(w2.size() == 4 && dump.model.dumped.size() == text.size() + 4);
+    }
     // Constructor::compute asserts the exact size (src/saca.rs:369)
     try { dark::saca::Constructor c(5); c.compute(bytes("banana")); return 1; } catch (const dark::Error &) {}
     std::puts("cpp mirror tests ok");
