@@ -174,6 +174,10 @@ def test_mirror_interfaces(vectors, license_bytes):
         stream = enc.encode(data)
         dec = block.dc.Decoder(len(data), enc.model)
         assert dec.decode(stream) == data
+    enc = block.raw.Encoder(len(license_bytes), "bbb")    # src/block/raw.rs with the coding model of src/main.rs:73,104
+    assert block.raw.Decoder(len(license_bytes), enc.model).decode(enc.encode(license_bytes)) == license_bytes
+    dump = block.raw.Encoder(len(license_bytes), "raw")
+    assert dump.encode(license_bytes) == b"\0\0\0\0" and len(dump.dumped) == len(license_bytes) + 4
 
 
 def test_cli_container(tmp_path, orc, license_bytes, monkeypatch):
