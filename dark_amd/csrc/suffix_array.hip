@@ -1,15 +1,19 @@
-// Suffix array by GPU prefix doubling over the device radix sort.  Replaces saca::Constructor::compute
-// (src/saca.rs:368-378) and with it all of saca() (src/saca.rs:270-340); the result is the same array: the suffix
-// array is unique, and like the reference there is no sentinel -- a suffix that is a proper prefix of another sorts first.
+// Suffix array on the GPU: radix sort on a packed prefix, text-extension rounds, then prefix doubling.  Replaces
+// saca::Constructor::compute (src/saca.rs:368-378) and with it all of saca() (src/saca.rs:270-340); the result is the same array: the
+// suffix array is unique, and like the reference there is no sentinel -- a suffix that is a proper prefix of another sorts first.
 //
 //   1. k_sym_hist        byte histogram -> host picks an order-preserving code of b = ceil(log2 sigma) bits per symbol
-//   2. k_pack_keys       key[i] = the first s = floor(64/b) symbols of suffix i, packed big-endian, zero padded
-//   3. sort_pairs        (key, i) by key                                  -> order by the first s symbols
-//   4. rerank            heads where the key changes; rank[i] = position of its group's head; singletons are final
-//                        (written to SA), the rest are compacted into the ACTIVE list (idx, slot position, group id)
-//   5. while active:     key = (group id, rank2) with rank2 = rank[i+h]+h, or n-1-i for i+h >= n (shorter is smaller);
-//                        sort_pairs on exactly the bits in use; rerank; h *= 2
-// Only members of unresolved groups are ever sorted again (Larsson-Sadakane style filtering).
+//   2. k_prefix_probe    (large blocks) does a sample of suffixes separate on a short prefix already?  -> symbols the initial sort covers
+//   3. sort_pairs        (key, i) by key, key = the first s symbols of suffix i packed big-endian (+ the code of the symbol in FRONT of
+//                        the suffix in the low byte when the caller wants L: BwtCarry); the first pass builds the keys from the text
+//   4. rerank            heads where the key changes; singletons are final (written to SA, and L), the rest are compacted into the ACTIVE
+//                        list (idx, slot position, group id, symbol in front)
+//   5a. text rounds      every group sorted inside its slot range by the next 8 bytes of the text (k_round_local<true>); no ranks needed
+//   5b. rank array       built once, for what survived: rank[SA[p]] = p by a bucketed scatter, active suffixes get their head's position
+//   5c. doubling rounds  secondary key rank[i+h]+h (n-1-i past the end: shorter is smaller); general rounds (k_round_local<false>, big
+//                        groups through the global sort, rerank) while groups of more than 256 members exist, then in-place rounds
+//                        (k_plateau_sort / k_plateau_ranks: no compaction, no scan, live count read back one round late)
+// Only members of unresolved groups are ever sorted again (Larsson-Sadakane style filtering).  DESIGN.md section 4.1.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
