@@ -319,7 +319,8 @@ def main():
     # block 0 of every repetition is the input itself, whose stream must equal the single-block path's.
     pipelined = None
     if args.pipeline_blocks > 0:
-        B = max(2, min(args.pipeline_blocks, int(2.4e9 // n)))  # bound pinned staging (about 3 bytes per input byte per block)
+        B = max(2, min(args.pipeline_blocks, int(2.4e9 // n), 3 * args.pipeline_threads))  # bound pinned staging (about 3 bytes per
+        # input byte per block) and, on a small CPU share, the leg's duration (one serial coding pass per block and thread)
         # one serial coding pass per block and worker: a block count that is a multiple of the workers keeps every worker busy to the
         # end (16 blocks on 15 workers would spend half of the time on the sixteenth)
         if B > args.pipeline_threads:
