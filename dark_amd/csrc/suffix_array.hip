@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void k_big_apply(const uint32_t *__restrict__ 
     uint32_t run = part[blockIdx.x] + block_excl_sum<RR_WAVES>(sum, s_tmp, nullptr);
 #pragma unroll
     for (int j = 0; j < BG_IPT; ++j) {
-        if (g0 + j < groups) bigstart[g0 + j] = run;
+        if (g0 + j < groups && v[j]) bigstart[g0 + j] = run;  // read for big groups only (k_round_local)
         run += v[j];
     }
 }
