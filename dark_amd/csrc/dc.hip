@@ -13,7 +13,7 @@
 //   k_dc_runscan   exclusive sum of the run counts                     (run index of every tile's first new run)
 //   k_dc_carry_*   256-way "last non-empty" exclusive scan over tiles  (last occurrence before each tile, per symbol)
 //   k_dc_main      one wave per tile, 64 positions per step (lane = position); the 256-entry last-occurrence table lives in
-//                  wave-private LDS (s_pos / s_pr below), ranks are found lane-parallel, results go straight to the compact arrays
+//                  wave-private LDS (s_pr below), ranks are found lane-parallel, results go straight to the compact arrays
 //   k_dc_sweep     the final 256 distances
 // Algorithmic bytes: 3 n (three reads of L) + 6 m (dist, sym, rank per run) + 2 * 2 KiB per tile of tables.
 #include "context.hpp"
@@ -26,9 +26,11 @@ constexpr int DC_BLOCK = 256;
 constexpr int DC_WAVES = DC_BLOCK / 64;
 constexpr int DC_TILE = 4096;        // positions per wave
 constexpr int DC_PAD = 16;           // tile bytes start at offset 16 in LDS; byte 15 holds L[base-1]
-constexpr int DC_MAX_CHUNKS = 256;
+constexpr int DC_MAX_CHUNKS = 2048;   // workgroups of the carry scan's outer phases (phase B walks over them serially)
+constexpr int DC_CARRY_BATCH = 8;     // tiles whose table rows a carry thread loads before it touches any of them
 constexpr int DC_FEW_A = 12;         // case-A lanes per chunk up to which each gets its own ballot instead of the shift loop
 constexpr int DC_WIDE_B = 20;        // first occurrences per chunk above which their ranks are counted lane-parallel
+constexpr int DC_FEW_LATER = 16;     // wide tiles: lanes per chunk that are neither the first nor the second of their symbol up to which each finds its predecessor by itself
 
 // Stage L[base-1 .. base+DC_TILE] of one tile into wave-private LDS: s[DC_PAD + j] = L[base + j].
 __device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ L, size_t n, size_t base, uint8_t *s, int lane) {
@@ -115,13 +117,22 @@ __global__ __launch_bounds__(256) void k_dc_carry_a(const uint32_t *__restrict__
     const size_t g = blockIdx.x, t0 = g * tpc, t1 = t0 + tpc < ntiles ? t0 + tpc : ntiles;
     const int c = threadIdx.x;
     uint32_t lp = 0, lr = 0;
-    for (size_t t = t0; t < t1; ++t) {
-        const uint32_t p = tile_last[t * 256 + c];
-        if (p) {
-            const uint32_t r = tile_run_base[t] + tile_lrun[t * 256 + c];
-            tile_lrun[t * 256 + c] = r;
-            lp = p;
-            lr = r;
+    for (size_t t = t0; t < t1; t += DC_CARRY_BATCH) {  // the loads of a batch are independent of its stores: all in flight together
+        uint32_t p[DC_CARRY_BATCH], r[DC_CARRY_BATCH], b[DC_CARRY_BATCH];
+#pragma unroll
+        for (int k = 0; k < DC_CARRY_BATCH; ++k) {
+            const bool in = t + k < t1;
+            p[k] = in ? tile_last[(t + k) * 256 + c] : 0u;
+            r[k] = in ? tile_lrun[(t + k) * 256 + c] : 0u;
+            b[k] = in ? tile_run_base[t + k] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < DC_CARRY_BATCH; ++k) {
+            if (p[k]) {
+                lp = p[k];
+                lr = b[k] + r[k];
+                tile_lrun[(t + k) * 256 + c] = lr;
+            }
         }
     }
     chunk_last[g * 256 + c] = lp;
@@ -131,11 +142,22 @@ __global__ __launch_bounds__(256) void k_dc_carry_a(const uint32_t *__restrict__
 __global__ __launch_bounds__(256) void k_dc_carry_b(uint32_t *__restrict__ chunk_last, uint32_t *__restrict__ chunk_lrun, size_t nchunks) {
     const int c = threadIdx.x;
     uint32_t lp = 0, lr = 0;
-    for (size_t g = 0; g < nchunks; ++g) {
-        const uint32_t p = chunk_last[g * 256 + c], r = chunk_lrun[g * 256 + c];
-        chunk_last[g * 256 + c] = lp;
-        chunk_lrun[g * 256 + c] = lr;
-        if (p) { lp = p; lr = r; }
+    for (size_t g = 0; g < nchunks; g += DC_CARRY_BATCH) {
+        uint32_t p[DC_CARRY_BATCH], r[DC_CARRY_BATCH];
+#pragma unroll
+        for (int k = 0; k < DC_CARRY_BATCH; ++k) {
+            const bool in = g + k < nchunks;
+            p[k] = in ? chunk_last[(g + k) * 256 + c] : 0u;
+            r[k] = in ? chunk_lrun[(g + k) * 256 + c] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < DC_CARRY_BATCH; ++k) {
+            if (g + k < nchunks) {
+                chunk_last[(g + k) * 256 + c] = lp;
+                chunk_lrun[(g + k) * 256 + c] = lr;
+                if (p[k]) { lp = p[k]; lr = r[k]; }
+            }
+        }
     }
 }
 // phase C: tables become exclusive carries (last occurrence strictly before the tile)
@@ -145,18 +167,27 @@ __global__ __launch_bounds__(256) void k_dc_carry_c(uint32_t *__restrict__ tile_
     const size_t g = blockIdx.x, t0 = g * tpc, t1 = t0 + tpc < ntiles ? t0 + tpc : ntiles;
     const int c = threadIdx.x;
     uint32_t lp = chunk_last[g * 256 + c], lr = chunk_lrun[g * 256 + c];
-    for (size_t t = t0; t < t1; ++t) {
-        const uint32_t p = tile_last[t * 256 + c], r = tile_lrun[t * 256 + c];
-        tile_last[t * 256 + c] = lp;
-        tile_lrun[t * 256 + c] = lr;
-        if (p) { lp = p; lr = r; }
+    for (size_t t = t0; t < t1; t += DC_CARRY_BATCH) {
+        uint32_t p[DC_CARRY_BATCH], r[DC_CARRY_BATCH];
+#pragma unroll
+        for (int k = 0; k < DC_CARRY_BATCH; ++k) {
+            const bool in = t + k < t1;
+            p[k] = in ? tile_last[(t + k) * 256 + c] : 0u;
+            r[k] = in ? tile_lrun[(t + k) * 256 + c] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < DC_CARRY_BATCH; ++k) {
+            if (t + k < t1) {
+                tile_last[(t + k) * 256 + c] = lp;
+                tile_lrun[(t + k) * 256 + c] = lr;
+                if (p[k]) { lp = p[k]; lr = r[k]; }
+            }
+        }
     }
 }
 
-// LDS layout of a wave's tables.  s_pos (u32[256], the vector side): symbol c lives at word ((c & 63) << 2) | (c >> 6), so
-// that lane l owns the four consecutive words of symbols l, l+64, l+128, l+192 (one 16-byte read).  s_pr (uint2[256], the
-// scalar side): {last position + 1, run index + 1} of symbol c at index c (one 8-byte broadcast read / store).
-__device__ __forceinline__ uint32_t tab_index(uint32_t c) { return ((c & 63u) << 2) | (c >> 6); }
+// LDS table of a wave: s_pr (uint2[256]) = {last position + 1, run index + 1} of symbol c at index c.  Lane l also speaks for the
+// symbols l, l+64, l+128, l+192 when the whole table is compared against one position (`mine` below).
 
 // One v_writelane_b32: lane `sel` of `old` becomes the (wave-uniform) value.  gfx9 lets a VALU instruction read one SGPR only, so
 // the lane select goes through M0 (which does not count); M0 is saved and restored.
@@ -183,24 +214,25 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
                                                        uint32_t *__restrict__ init, uint32_t *__restrict__ final_last,
                                                        uint32_t *__restrict__ final_lrun) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[DC_WAVES][DC_PAD + DC_TILE + 16];
-    __shared__ __attribute__((aligned(16))) uint32_t s_pos[DC_WAVES][256];
     __shared__ __attribute__((aligned(16))) uint2 s_pr[DC_WAVES][256];
     __shared__ unsigned long long s_bm[DC_WAVES][DC_TILE / 64];  // wide tiles: bit j = position j of the tile is the last occurrence of its symbol
+    __shared__ uint32_t s_first[DC_WAVES][256];                  // wide tiles: first lane of every symbol of the current chunk (else ~0)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t tile = static_cast<size_t>(blockIdx.x) * DC_WAVES + wave;
     if (tile >= ntiles) return;
     const size_t base = tile * DC_TILE;
     uint8_t *s = s_tile[wave];
-    uint32_t *pos = s_pos[wave];
     uint2 *pr = s_pr[wave];
     unsigned long long *bm = s_bm[wave];
+    uint32_t *first_lane = s_first[wave];
     bm[lane] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) first_lane[k * 64 + lane] = ~0u;
     bool wide = false;  // wave-uniform, decided at the tile's first chunk
     stage_tile(L, n, base, s, lane);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t cp = carry_last[tile * 256 + k * 64 + lane], cr = carry_lrun[tile * 256 + k * 64 + lane];
-        pos[(lane << 2) | k] = cp;
         pr[k * 64 + lane] = make_uint2(cp, cr);
     }
     uint32_t r = __builtin_amdgcn_readfirstlane(tile_run_base[tile]);  // index of the next run to start (wave-uniform)
@@ -226,31 +258,81 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
                     if (old1 > base32) bm[(old1 - 1u - base32) >> 6] &= ~(1ull << ((old1 - 1u - base32) & 63u));
                     bm[chunk] = 1ull << lane;
                 }
-                pos[tab_index(c)] = p1;
                 pr[c] = make_uint2(p1, r);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             continue;
         }
-        uint64_t same = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (c >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
-            same &= bit ? bal : ~bal;
+        // ---- previous lane with my symbol inside this chunk (-1: none), and the lanes that have such a lane after them
+        int prevsame;
+        uint64_t notlast;  // wave-uniform
+        bool matched = false;
+        if (wide) {
+            // Large alphabets: nearly every lane is the first of its symbol, a few are the second, hardly any the third.  The first lane
+            // of every symbol comes from one LDS min per lane, the second from another min among the rest (its predecessor is the first);
+            // what is left after that looks for its predecessor lane by lane.
+            if (valid) atomicMin(&first_lane[c], static_cast<uint32_t>(lane));
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t f1 = first_lane[c];
+            const bool first = valid && f1 == static_cast<uint32_t>(lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (first) first_lane[c] = ~0u;
+            const bool later = valid && !first;
+            uint32_t f2 = ~0u;
+            bool second = false;
+            if (__ballot(later)) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (later) atomicMin(&first_lane[c], static_cast<uint32_t>(lane));
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                f2 = first_lane[c];
+                second = later && f2 == static_cast<uint32_t>(lane);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (second) first_lane[c] = ~0u;
+            }
+            prevsame = first ? -1 : static_cast<int>(f1);  // right for the seconds; the others are corrected below
+            notlast = __ballot(first && f2 != ~0u);
+            uint64_t rest = __ballot(later && !second);
+            if (__popcll(rest) <= DC_FEW_LATER) {
+                while (rest) {
+                    const int bit = __builtin_ctzll(rest);
+                    rest &= rest - 1;
+                    const uint32_t v = __builtin_amdgcn_readlane(c, bit);
+                    const uint64_t m = __ballot(valid && c == v) & ((1ull << bit) - 1ull);  // not empty: `bit` is not the first of its symbol
+                    const int w = 63 - __builtin_clzll(m);
+                    prevsame = static_cast<int>(write_lane(static_cast<uint32_t>(w), bit, static_cast<uint32_t>(prevsame)));
+                    notlast |= 1ull << w;
+                }
+                matched = true;
+            }
         }
-        const uint64_t before = same & lt;
-        const int prevsame = before ? 63 - __builtin_clzll(before) : -1;  // previous lane with my symbol in this chunk
+        if (!matched) {
+            uint64_t same = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (c >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                same &= bit ? bal : ~bal;
+            }
+            const uint64_t before = same & lt;
+            prevsame = before ? 63 - __builtin_clzll(before) : -1;
+            notlast = __ballot((same & ~le) != 0);
+        }
         const uint2 tab = pr[c];                                           // table state BEFORE this chunk: {pos+1, run+1}
-        const uint4 mine = *reinterpret_cast<const uint4 *>(pos + (lane << 2));
+        const uint4 mine = make_uint4(pr[lane].x, pr[64 + lane].x, pr[128 + lane].x, pr[192 + lane].x);
         const bool isA = start && prevsame >= 0;
         const bool isB = start && prevsame < 0;
         // ---- case A: distinct symbols in lanes (w, lane)
         uint32_t cnt = 0;
         uint64_t mA = __ballot(isA);
-        if (__popcll(mA) <= DC_FEW_A) {
-            // few such lanes (large alphabets): one ballot each -- the lanes that are first of their symbol after w, cut to (w, lane)
+        if (mA == 0) {
+        } else if (!wide && __popcll(mA) <= DC_FEW_A) {
+            // few such lanes: one ballot each -- the lanes that are first of their symbol after w, cut to (w, lane)
             while (mA) {
                 const int bit = __builtin_ctzll(mA);
                 mA &= mA - 1;
@@ -260,14 +342,11 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
                 cnt = write_lane(static_cast<uint32_t>(__popcll(firsts & window)), bit, cnt);
             }
         } else {
-            const int w = prevsame;
-            int sh = prevsame;
-            for (int t = 1; t < 64; ++t) {
-                sh = __shfl_up(sh, 1, 64);  // lane l now holds prevsame[l - t]
-                const bool need = isA && t < lane - w;
-                if (__ballot(need) == 0) break;
-                cnt += (need && sh <= w) ? 1u : 0u;
-            }
+            // many such lanes (small alphabets): the lanes q < lane whose predecessor lies at or before w are the w + 1 lanes up to w
+            // (their predecessor is before themselves) and the firsts inside the window -- a dominance count on key = predecessor + 1
+            // (six bits; the keys above zero are distinct, and mine is above zero)
+            const uint32_t dom = wave_dominance<6>(static_cast<uint32_t>(prevsame + 1), __ballot(valid) & lt);
+            if (isA) cnt = dom - static_cast<uint32_t>(prevsame + 1);
         }
         // ---- case B: first occurrence of the symbol in this chunk; the previous one (if any) is in the table
         const bool first_here = valid && prevsame < 0;
@@ -294,21 +373,12 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
             // + the symbols first seen in this chunk in an EARLIER lane whose own previous occurrence is not after mine (their mark sits
             // at or before b, so the bitmap did not count them).  A dominance count over at most 64 lanes: previous occurrences before
             // the tile (or none) always qualify -- one ballot; among the in-tile ones the previous positions are distinct 12-bit
-            // numbers, compared bit-sliced from the top: E = the earlier lanes that still agree with me on the bits seen so far; where
-            // my bit is 1, those of them with a 0 are smaller.  12 x (ballot, and, popcount) instead of a scalar loop over ~57 lanes.
+            // numbers, compared bit-sliced (wave_dominance) instead of a scalar loop over ~57 lanes.
             {
                 const uint64_t outside = __ballot(first_here && !in_tile);
                 const bool memb = first_here && in_tile;
                 const uint32_t K = memb ? (b1 - 1u - base32) : 0u;  // position of my previous occurrence inside the tile
-                uint64_t E = __ballot(memb) & lt;
-                uint32_t dom = static_cast<uint32_t>(__popcll(outside & lt));
-#pragma unroll
-                for (int k = 11; k >= 0; --k) {
-                    const bool bit = (K >> k) & 1u;
-                    const uint64_t B = __ballot(bit);
-                    dom += bit ? static_cast<uint32_t>(__popcll(E & ~B)) : 0u;
-                    E &= bit ? B : ~B;
-                }
+                const uint32_t dom = static_cast<uint32_t>(__popcll(outside & lt)) + wave_dominance<12>(K, __ballot(memb) & lt);
                 rk += dom;
             }
             if (isB) cnt = in_tile ? rk : 0u;
@@ -324,13 +394,13 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
             }
         } else if (__popcll(mB) > DC_WIDE_B) {
             // many first occurrences (large alphabets: random bytes have ~57 per chunk): every lane counts for itself -- the 256 table
-            // positions arrive as 64 broadcast 16-byte LDS reads, then the symbols first seen earlier in this chunk
+            // positions arrive as 128 broadcast 16-byte LDS reads, then the symbols first seen earlier in this chunk
             const uint32_t b1 = tab.x;
             uint32_t rk = 0;
 #pragma unroll 4
-            for (int t = 0; t < 64; ++t) {
-                const uint4 e = *reinterpret_cast<const uint4 *>(pos + 4 * t);
-                rk += (e.x > b1 ? 1u : 0u) + (e.y > b1 ? 1u : 0u) + (e.z > b1 ? 1u : 0u) + (e.w > b1 ? 1u : 0u);
+            for (int t = 0; t < 128; ++t) {
+                const uint4 e = *reinterpret_cast<const uint4 *>(pr + 2 * t);  // two entries {position, run}
+                rk += (e.x > b1 ? 1u : 0u) + (e.z > b1 ? 1u : 0u);
             }
             uint64_t fm = __ballot(first_here);
             while (fm) {
@@ -357,14 +427,17 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
         }
         // ---- outputs of the run-start lanes
         const uint32_t r0 = r;
+        const uint32_t starts_before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(S >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(S), 0u));
+        // run starts in lanes 0 .. w, fetched from lane w (lanes without a predecessor read their own)
+        const uint32_t starts_upto_w = static_cast<uint32_t>(__shfl(static_cast<int>(starts_before + (start ? 1u : 0u)), prevsame >= 0 ? prevsame : lane, 64));
         if (start) {
             const uint32_t i = base32 + static_cast<uint32_t>(j);
-            const uint32_t ridx = r0 + static_cast<uint32_t>(__popcll(S & lt));
+            const uint32_t ridx = r0 + starts_before;
             sym[ridx] = static_cast<uint8_t>(c);
             if (rank) rank[ridx] = static_cast<uint8_t>(cnt);
             if (isA) {
                 const uint32_t b1 = base32 + static_cast<uint32_t>(chunk * 64 + prevsame) + 1u;
-                const uint32_t prun = r0 + static_cast<uint32_t>(__popcll(S & ((2ull << prevsame) - 1ull))) - 1u;  // run of lane w
+                const uint32_t prun = r0 + starts_upto_w - 1u;  // run of lane w
                 dist[prun] = i - b1 - cnt;  // = i - b - rank - 1 with b = b1 - 1
             } else if (tab.x) {
                 dist[tab.y - 1] = i - tab.x - cnt;
@@ -375,7 +448,7 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
         }
         // ---- table update: the last lane of every symbol of this chunk
         __builtin_amdgcn_wave_barrier();
-        const bool last_here = valid && (same & ~le) == 0;
+        const bool last_here = valid && !((notlast >> lane) & 1ull);
         if (wide) {  // marks of the symbols of this chunk move to their last lane here
             if (last_here && tab.x > base32) atomicAnd(&bm[(tab.x - 1u - base32) >> 6], ~(1ull << ((tab.x - 1u - base32) & 63u)));
             const uint64_t lm = __ballot(last_here);
@@ -383,8 +456,7 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
         }
         if (last_here) {
             const uint32_t p1 = base32 + static_cast<uint32_t>(j) + 1u;
-            const uint32_t run1 = r0 + static_cast<uint32_t>(__popcll(S & le));  // (index of the run holding this lane) + 1
-            pos[tab_index(c)] = p1;
+            const uint32_t run1 = r0 + starts_before + (start ? 1u : 0u);  // (index of the run holding this lane) + 1
             pr[c] = make_uint2(p1, run1);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
