@@ -26,7 +26,7 @@ constexpr int DC_BLOCK = 256;
 constexpr int DC_WAVES = DC_BLOCK / 64;
 constexpr int DC_TILE = 4096;        // positions per wave
 constexpr int DC_PAD = 16;           // tile bytes start at offset 16 in LDS; byte 15 holds L[base-1]
-constexpr int DC_MAX_CHUNKS = 2048;   // workgroups of the carry scan's outer phases (phase B walks over them serially)
+constexpr int DC_MAX_CHUNKS = 512;    // workgroups of the carry scan's outer phases (phase B is one workgroup walking over all of them)
 constexpr int DC_CARRY_BATCH = 8;     // tiles whose table rows a carry thread loads before it touches any of them
 constexpr int DC_FEW_A = 12;         // case-A lanes per chunk up to which each gets its own ballot instead of the shift loop
 constexpr int DC_WIDE_B = 20;        // first occurrences per chunk above which their ranks are counted lane-parallel
@@ -138,21 +138,45 @@ __global__ __launch_bounds__(256) void k_dc_carry_a(const uint32_t *__restrict__
     chunk_last[g * 256 + c] = lp;
     chunk_lrun[g * 256 + c] = lr;
 }
-// phase B (one workgroup): exclusive over chunks
-__global__ __launch_bounds__(256) void k_dc_carry_b(uint32_t *__restrict__ chunk_last, uint32_t *__restrict__ chunk_lrun, size_t nchunks) {
-    const int c = threadIdx.x;
+// phase B (one workgroup of four quarters): exclusive over chunks.  Every quarter of the chunk range first finds its own last
+// non-empty entry per symbol, takes the carry of the quarters before it through LDS, and then rewrites its rows.
+__global__ __launch_bounds__(1024) void k_dc_carry_b(uint32_t *__restrict__ chunk_last, uint32_t *__restrict__ chunk_lrun, size_t nchunks) {
+    __shared__ uint32_t s_lp[4][256], s_lr[4][256];
+    const int c = threadIdx.x & 255, q = threadIdx.x >> 8;
+    const size_t per = (nchunks + 3) / 4;
+    const size_t g0 = static_cast<size_t>(q) * per < nchunks ? static_cast<size_t>(q) * per : nchunks;
+    const size_t g1 = g0 + per < nchunks ? g0 + per : nchunks;
     uint32_t lp = 0, lr = 0;
-    for (size_t g = 0; g < nchunks; g += DC_CARRY_BATCH) {
+    for (size_t g = g0; g < g1; g += DC_CARRY_BATCH) {
         uint32_t p[DC_CARRY_BATCH], r[DC_CARRY_BATCH];
 #pragma unroll
         for (int k = 0; k < DC_CARRY_BATCH; ++k) {
-            const bool in = g + k < nchunks;
+            const bool in = g + k < g1;
+            p[k] = in ? chunk_last[(g + k) * 256 + c] : 0u;
+            r[k] = in ? chunk_lrun[(g + k) * 256 + c] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < DC_CARRY_BATCH; ++k)
+            if (p[k]) { lp = p[k]; lr = r[k]; }
+    }
+    s_lp[q][c] = lp;
+    s_lr[q][c] = lr;
+    __syncthreads();
+    lp = 0;
+    lr = 0;
+    for (int k = 0; k < q; ++k)
+        if (s_lp[k][c]) { lp = s_lp[k][c]; lr = s_lr[k][c]; }
+    for (size_t g = g0; g < g1; g += DC_CARRY_BATCH) {
+        uint32_t p[DC_CARRY_BATCH], r[DC_CARRY_BATCH];
+#pragma unroll
+        for (int k = 0; k < DC_CARRY_BATCH; ++k) {
+            const bool in = g + k < g1;
             p[k] = in ? chunk_last[(g + k) * 256 + c] : 0u;
             r[k] = in ? chunk_lrun[(g + k) * 256 + c] : 0u;
         }
 #pragma unroll
         for (int k = 0; k < DC_CARRY_BATCH; ++k) {
-            if (g + k < nchunks) {
+            if (g + k < g1) {
                 chunk_last[(g + k) * 256 + c] = lp;
                 chunk_lrun[(g + k) * 256 + c] = lr;
                 if (p[k]) { lp = p[k]; lr = r[k]; }
@@ -372,13 +396,15 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
             uint32_t rk = total - below;
             // + the symbols first seen in this chunk in an EARLIER lane whose own previous occurrence is not after mine (their mark sits
             // at or before b, so the bitmap did not count them).  A dominance count over at most 64 lanes: previous occurrences before
-            // the tile (or none) always qualify -- one ballot; among the in-tile ones the previous positions are distinct 12-bit
-            // numbers, compared bit-sliced (wave_dominance) instead of a scalar loop over ~57 lanes.
+            // the tile (or none) always qualify -- one ballot; the in-tile ones are compared bit-sliced (wave_dominance) instead of by
+            // a scalar loop over ~57 lanes.
             {
                 const uint64_t outside = __ballot(first_here && !in_tile);
                 const bool memb = first_here && in_tile;
-                const uint32_t K = memb ? (b1 - 1u - base32) : 0u;  // position of my previous occurrence inside the tile
-                const uint32_t dom = static_cast<uint32_t>(__popcll(outside & lt)) + wave_dominance<12>(K, __ballot(memb) & lt);
+                // my previous occurrence is itself a marked position, so `below` is its place among the marks (1 .. 256): an eight-bit key
+                // that orders the members as their positions do
+                const uint32_t K = memb ? below - 1u : 0u;
+                const uint32_t dom = static_cast<uint32_t>(__popcll(outside & lt)) + wave_dominance<8>(K, __ballot(memb) & lt);
                 rk += dom;
             }
             if (isB) cnt = in_tile ? rk : 0u;
@@ -435,20 +461,16 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
             const uint32_t ridx = r0 + starts_before;
             sym[ridx] = static_cast<uint8_t>(c);
             if (rank) rank[ridx] = static_cast<uint8_t>(cnt);
-            if (isA) {
-                const uint32_t b1 = base32 + static_cast<uint32_t>(chunk * 64 + prevsame) + 1u;
-                const uint32_t prun = r0 + starts_upto_w - 1u;  // run of lane w
-                dist[prun] = i - b1 - cnt;  // = i - b - rank - 1 with b = b1 - 1
-            } else if (tab.x) {
-                dist[tab.y - 1] = i - tab.x - cnt;
-            } else {
-                init[c] = i;  // first occurrence in the block
-            }
+            // previous occurrence b (as b + 1; 0 = none) and the run it closed: lane w of this chunk, or the table's
+            const uint32_t b1 = isA ? base32 + static_cast<uint32_t>(chunk * 64 + prevsame) + 1u : tab.x;
+            const uint32_t prun = isA ? r0 + starts_upto_w - 1u : tab.y - 1u;
+            if (b1) dist[prun] = i - b1 - cnt;  // = i - b - rank - 1
+            else init[c] = i;                   // first occurrence in the block
             if (run_end && ridx > 0) run_end[ridx - 1] = i - 1;
         }
         // ---- table update: the last lane of every symbol of this chunk
         __builtin_amdgcn_wave_barrier();
-        const bool last_here = valid && !((notlast >> lane) & 1ull);
+        const bool last_here = valid && !__builtin_amdgcn_inverse_ballot_w64(notlast);
         if (wide) {  // marks of the symbols of this chunk move to their last lane here
             if (last_here && tab.x > base32) atomicAnd(&bm[(tab.x - 1u - base32) >> 6], ~(1ull << ((tab.x - 1u - base32) & 63u)));
             const uint64_t lm = __ballot(last_here);
@@ -519,7 +541,7 @@ int dc_encode_device(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t init_
         LaunchScope ls(ctx, K_DC_CARRY, 3.0 * 2048.0 * ntiles);
         k_dc_runscan<<<dim3(1), dim3(1024), 0, st>>>(tile_runs, ntiles, ctx->d_mail);
         k_dc_carry_a<<<dim3(nchunks), dim3(256), 0, st>>>(tile_last, tile_lrun, tile_runs, ntiles, tpc, chunk_last, chunk_lrun);
-        k_dc_carry_b<<<dim3(1), dim3(256), 0, st>>>(chunk_last, chunk_lrun, nchunks);
+        k_dc_carry_b<<<dim3(1), dim3(1024), 0, st>>>(chunk_last, chunk_lrun, nchunks);
         k_dc_carry_c<<<dim3(nchunks), dim3(256), 0, st>>>(tile_last, tile_lrun, ntiles, tpc, chunk_last, chunk_lrun);
         k_fill_u32<<<dim3(1), dim3(256), 0, st>>>(d_init, 256, static_cast<uint32_t>(n));
     }
