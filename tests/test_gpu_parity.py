@@ -336,3 +336,45 @@ def test_batch_encode_matches_single(ctx, orc):
     with pytest.raises(dark_amd.DarkError):  # a stream cut short fails its block and the call, it does not hang the pool
         ctx.dev_batch_decode("dark", [streams[0][:40]] + list(streams), [len(blocks[0])] + [len(b) for b in blocks[:2]],
                              [d_outs[0]] + d_outs[:2], host_threads=2)
+
+
+def test_dc_path_mixtures(ctx, orc):
+    """k_dc_main picks its way per tile (wide: more than 20 distinct symbols in the tile's first 64 positions) and per chunk of 64
+    (how many lanes are the first / second / a later occurrence of their symbol, how many first occurrences): byte arrays built to
+    land on every combination, compared with the oracle's bwt::dc::encode restatement (any byte array is a valid input of the stage)."""
+    rng = np.random.default_rng(4711)
+    T = 4096
+
+    def tiles(head, body, count=5, tail=1234):
+        out = []
+        for k in range(count):
+            out.append(head(64))
+            out.append(body(T - 64))
+        out.append(body(tail))
+        return np.concatenate(out).astype(np.uint8)
+
+    rnd = lambda a: (lambda m: rng.integers(0, a, m))
+    period = lambda p: (lambda m: (np.arange(m) % p) + 7)
+    runs = lambda m: np.repeat(rng.integers(0, 9, m // 5 + 1), 5)[:m]
+    cases = [
+        tiles(rnd(256), period(2)),             # wide tile, then chunks where 60 lanes are a third or later occurrence (bit-matching fallback)
+        tiles(rnd(256), period(3)),
+        tiles(rnd(256), period(40)),            # wide tile, every chunk: 40 firsts, 24 seconds
+        tiles(rnd(256), runs),                  # wide tile, then long runs (chunks without any run start)
+        tiles(period(2), rnd(256)),             # narrow tile whose later chunks have ~57 first occurrences (whole-table route)
+        tiles(rnd(256), lambda m: np.where(np.arange(m) // 64 % 2 == 0, rng.integers(0, 256, m), 5)),  # random chunks between constant ones
+        rng.integers(0, 40, 3 * T + 17),        # 40 symbols: ~14 lanes per chunk beyond the second occurrence, either side of the threshold
+        rng.integers(0, 24, 3 * T + 999),       # 24 symbols: wide or not from tile to tile
+        rng.integers(0, 90, 2 * T + 63),
+        rng.integers(0, 256, 8 * T + 1),        # the bitmap route proper
+        np.concatenate([rng.integers(0, 256, 70), np.full(3 * T, 200)]),  # a wide tile whose symbols never come back
+        np.concatenate([rng.integers(0, 256, T), rng.integers(0, 4, T), rng.integers(0, 256, T + 5)]),
+    ]
+    for k, L in enumerate(cases):
+        L = np.ascontiguousarray(L, dtype=np.uint8)
+        want = orc.dc_encode(L)
+        got = ctx.dc_encode(L)
+        for key in ("init", "d", "sym", "rank"):
+            assert first_diff(got[key], want[key]) is None, (k, "dc." + key, len(L), first_diff(got[key], want[key]))
+        out, used = orc.dc_decode(got["init"], got["d"], len(L))
+        assert used == len(got["d"]) and first_diff(out, L) is None, (k, "dc round trip")
