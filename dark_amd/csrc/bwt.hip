@@ -123,22 +123,15 @@ __global__ __launch_bounds__(IB_BLOCK) void k_ibwt_lf(const uint8_t *__restrict_
         sym[k] = i < n ? bwt[i] : 0x100u;  // 0x100 = padding, ranked but never stored
     }
     __syncthreads();
-    const uint64_t lt = lanemask_lt(lane);
 #pragma unroll
     for (int k = 0; k < IB_SPT; ++k) {
         const uint32_t d = sym[k] & 0xFFu;
         const bool pad = sym[k] > 0xFFu;
-        uint64_t same = __ballot(!pad);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
-            same &= bit ? bal : ~bal;
-        }
-        const uint32_t before = static_cast<uint32_t>(__popcll(same & lt));
+        const LaneSet same = wave_match<8>(d, __ballot(!pad));
+        const uint32_t before = same.before();
         const uint32_t old = pad ? 0u : s_cnt[wave][d];
         __builtin_amdgcn_wave_barrier();
-        if (!pad && before == 0) s_cnt[wave][d] = old + static_cast<uint32_t>(__popcll(same));
+        if (!pad && before == 0) s_cnt[wave][d] = old + same.count();
         __builtin_amdgcn_wave_barrier();
         rnk[k] = old + before;
     }

@@ -336,13 +336,7 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
             }
         }
         if (!matched) {
-            uint64_t same = __ballot(valid);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bool bit = (c >> b) & 1u;
-                const uint64_t bal = __ballot(bit);
-                same &= bit ? bal : ~bal;
-            }
+            const uint64_t same = wave_match<8>(c, __ballot(valid)).mask();
             const uint64_t before = same & lt;
             prevsame = before ? 63 - __builtin_clzll(before) : -1;
             notlast = __ballot((same & ~le) != 0);

@@ -39,6 +39,30 @@ __device__ __forceinline__ uint32_t wave_incl_max(uint32_t v, int /*lane*/) {
     return v;
 }
 
+// A set of lanes as two 32-bit halves in vector registers (a per-lane 64-bit value costs two instructions per operation either way;
+// keeping the halves apart lets every step be the one instruction it is).
+struct LaneSet {
+    uint32_t lo, hi;
+    __device__ __forceinline__ uint32_t count() const { return static_cast<uint32_t>(__popc(lo) + __popc(hi)); }
+    // members below this lane (v_mbcnt: population count under the lane's own "lanes before me" mask)
+    __device__ __forceinline__ uint32_t before() const { return __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u)); }
+    __device__ __forceinline__ uint64_t mask() const { return (static_cast<uint64_t>(hi) << 32) | lo; }
+};
+// wave64 match-any: the lanes of `among` that hold the same BITS-bit value as this lane.  One ballot per bit; a lane keeps the lanes
+// that agree with it at that bit (xnor of the ballot with its own bit spread over a word): six vector instructions per bit.
+template <int BITS>
+__device__ __forceinline__ LaneSet wave_match(uint32_t v, uint64_t among) {
+    LaneSet s{static_cast<uint32_t>(among), static_cast<uint32_t>(among >> 32)};
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) {
+        const uint32_t ones = static_cast<uint32_t>(static_cast<int32_t>(v << (31 - b)) >> 31);  // all ones where my bit b is set
+        const uint64_t B = __ballot(ones != 0);
+        s.lo &= ~(static_cast<uint32_t>(B) ^ ones);
+        s.hi &= ~(static_cast<uint32_t>(B >> 32) ^ ones);
+    }
+    return s;
+}
+
 // For every lane: how many EARLIER lanes (bit set in `earlier` = a set of lanes below mine) hold a smaller key.  The keys of the lanes that
 // matter are distinct numbers below 2^BITS; a lane holding my own key is not counted.  Bit-sliced from the top: E = the earlier lanes that
 // agree with me on the bits seen so far; at a bit where I have a one, those of them with a zero are smaller -- they leave E into U, the

@@ -231,8 +231,12 @@ __global__ __launch_bounds__(256) void k_radix_scan_c(uint32_t *__restrict__ til
 }
 
 // tile_offs: the scanned per-tile digit offsets.  xcd_tiles != 0: XCD-aware tile order over a grid of 8 * ceil(ntiles / 8) blocks.
+// Three workgroups per CU, not the four that registers and LDS would allow: with a fourth tile in flight per CU the L2 no longer
+// merges the short output runs of neighbouring tiles before it has to evict them (measured, 1e8 text: 3.95 ms of scatter per sort
+// against 3.6 ms; two per CU: 3.65 ms but slower overall).  The kernel is bound by that, not by its ballots: a third fewer vector
+// instructions in the ranking (wave_match) did not move it.
 template <bool PAIRS = false, bool TEXT = false>
-__global__ __launch_bounds__(RS_BLOCK) void k_radix_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+__global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_radix_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                              const uint32_t *__restrict__ pair_lo,
                                                              uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n,
                                                              int shift, const uint32_t *__restrict__ tile_offs, uint32_t xcd_tiles,
@@ -291,21 +295,14 @@ __global__ __launch_bounds__(RS_BLOCK) void k_radix_scatter(const uint64_t *__re
 
     // stable rank inside the wave: lanes holding the same digit find each other with 8 ballots
     uint32_t rnk[RS_KPT];
-    const uint64_t lt = lanemask_lt(lane);
 #pragma unroll
     for (int k = 0; k < RS_KPT; ++k) {
         const uint32_t d = digit_of(key[k], shift);
-        uint64_t same = ~0ull;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
-            same &= bit ? bal : ~bal;
-        }
-        const uint32_t before = static_cast<uint32_t>(__popcll(same & lt));
+        const LaneSet same = wave_match<8>(d, ~0ull);
+        const uint32_t before = same.before();
         const uint32_t old = s_cnt[wave][d];
         __builtin_amdgcn_wave_barrier();
-        if (before == 0) s_cnt[wave][d] = old + static_cast<uint32_t>(__popcll(same));
+        if (before == 0) s_cnt[wave][d] = old + same.count();
         __builtin_amdgcn_wave_barrier();
         rnk[k] = old + before;
     }
@@ -380,7 +377,6 @@ __global__ __launch_bounds__(SS_BLOCK) void k_radix_sort_small(uint64_t *__restr
     __shared__ uint32_t s_start[256];
     __shared__ uint32_t s_tmp[SS_WAVES + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t lt = lanemask_lt(lane);
     // wave w owns positions [w * 512, (w + 1) * 512), lane-striped: position order = (wave, k, lane)
     const uint32_t wbase = static_cast<uint32_t>(wave) * (64 * SS_KPT);
     uint64_t key[SS_KPT];
@@ -398,17 +394,11 @@ __global__ __launch_bounds__(SS_BLOCK) void k_radix_sort_small(uint64_t *__restr
 #pragma unroll
         for (int k = 0; k < SS_KPT; ++k) {
             const uint32_t d = digit_of(key[k], shift);
-            uint64_t same = ~0ull;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bool bit = (d >> b) & 1u;
-                const uint64_t bal = __ballot(bit);
-                same &= bit ? bal : ~bal;
-            }
-            const uint32_t before = static_cast<uint32_t>(__popcll(same & lt));
+            const LaneSet same = wave_match<8>(d, ~0ull);
+            const uint32_t before = same.before();
             const uint32_t old = s_cnt[wave][d];
             __builtin_amdgcn_wave_barrier();
-            if (before == 0) s_cnt[wave][d] = old + static_cast<uint32_t>(__popcll(same));
+            if (before == 0) s_cnt[wave][d] = old + same.count();
             __builtin_amdgcn_wave_barrier();
             rnk[k] = old + before;
         }
