@@ -28,24 +28,27 @@ constexpr int DC_TILE = 4096;        // positions per wave
 constexpr int DC_PAD = 16;           // tile bytes start at offset 16 in LDS; byte 15 holds L[base-1]
 constexpr int DC_MAX_CHUNKS = 512;    // workgroups of the carry scan's outer phases (phase B is one workgroup walking over all of them)
 constexpr int DC_CARRY_BATCH = 8;     // tiles whose table rows a carry thread loads before it touches any of them
+constexpr uint32_t DC_WINDOW = 4096;  // positions before the tile that the bitmap of a wide tile covers as well
+constexpr int DC_BM_WORDS = (DC_TILE + DC_WINDOW) / 64;
 constexpr int DC_FEW_A = 12;         // case-A lanes per chunk up to which each gets its own ballot instead of the shift loop
 constexpr int DC_WIDE_B = 20;        // first occurrences per chunk above which their ranks are counted lane-parallel
 constexpr int DC_FEW_LATER = 16;     // wide tiles: lanes per chunk that are neither the first nor the second of their symbol up to which each finds its predecessor by itself
 
-// Stage L[base-1 .. base+DC_TILE] of one tile into wave-private LDS: s[DC_PAD + j] = L[base + j].
+// Stage one tile into wave-private LDS: s[PAD + j] = L[base + j]; with PAD > 0 also its neighbours L[base-1] and L[base+DC_TILE].
+template <int PAD>
 __device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ L, size_t n, size_t base, uint8_t *s, int lane) {
     const bool aligned = (reinterpret_cast<uintptr_t>(L) & 15) == 0;
     for (int j = lane * 16; j < DC_TILE; j += 64 * 16) {
         const size_t p = base + j;
         if (aligned && p + 16 <= n) {
-            *reinterpret_cast<uint4 *>(s + DC_PAD + j) = *reinterpret_cast<const uint4 *>(L + p);
+            *reinterpret_cast<uint4 *>(s + PAD + j) = *reinterpret_cast<const uint4 *>(L + p);
         } else {
-            for (int b = 0; b < 16; ++b) s[DC_PAD + j + b] = (p + b < n) ? L[p + b] : 0;
+            for (int b = 0; b < 16; ++b) s[PAD + j + b] = (p + b < n) ? L[p + b] : 0;
         }
     }
-    if (lane == 0) {
-        s[DC_PAD - 1] = base > 0 ? L[base - 1] : 0;
-        s[DC_PAD + DC_TILE] = (base + DC_TILE < n) ? L[base + DC_TILE] : 0;
+    if (PAD > 0 && lane == 0) {
+        s[PAD - 1] = base > 0 ? L[base - 1] : 0;
+        s[PAD + DC_TILE] = (base + DC_TILE < n) ? L[base + DC_TILE] : 0;
     }
 }
 
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_summary(const uint8_t *__restri
     const size_t base = tile * DC_TILE;
     uint8_t *s = s_tile[wave];
     for (int k = 0; k < 4; ++k) { s_last[wave][k * 64 + lane] = 0; s_lrun[wave][k * 64 + lane] = 0; }
-    stage_tile(L, n, base, s, lane);
+    stage_tile<DC_PAD>(L, n, base, s, lane);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     uint32_t runs = 0;
@@ -223,23 +226,31 @@ __device__ __forceinline__ uint32_t write_lane(uint32_t value, int sel, uint32_t
     return old;
 }
 
-// One wave per tile.  Per 64-position chunk (lane = position) the ranks are found mostly lane-parallel:
+// One wave per tile.  Per 64-position chunk (lane = position) the ranks are found lane-parallel:
 //   case A  the run's symbol already occurred in this chunk, last at lane w: rank = number of lanes q in (w, lane) that are the
-//           first of their symbol inside that window (prevsame[q] <= w), counted by shifting prevsame one lane per step;
-//   case B  first occurrence of the symbol in this chunk: previous occurrence b from the tile table (state before the chunk),
+//           first of their symbol inside that window (prevsame[q] <= w) -- a dominance count on the predecessors (wave_dominance), or
+//           one ballot per such lane when they are few on a small alphabet;
+//   case B  first occurrence of the symbol in this chunk: previous occurrence b from the table (state before the chunk),
 //           rank = #{table symbols with last position > b} + #{symbols first seen in this chunk before the lane whose table
-//           position is <= b}; a short scalar loop over these lanes (at most one per distinct symbol of the chunk), or, when
-//           there are many of them, every lane for itself over the whole table.
-// Then every run-start lane stores its own outputs, and the last lane of every symbol updates the tile table.
+//           position is <= b}.  Small alphabets: a short scalar loop over these lanes (at most one per distinct symbol of the chunk),
+//           or, when there are many of them, every lane for itself over the whole table.  Large alphabets ("wide" tiles): a bitmap of
+//           last occurrences over the tile and the DC_WINDOW positions before it + a second dominance count.
+// Then every run-start lane stores its own outputs, and the last lane of every symbol updates the table (and the bitmap).
+// The kernel is bound by instruction issue and by the length of its dependent chains, not by memory: a loop
+// of a dozen scalar instructions per lane loses against sixty vector instructions for all lanes at once.
 __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict__ L, size_t n, size_t ntiles,
                                                        const uint32_t *__restrict__ carry_last, const uint32_t *__restrict__ carry_lrun,
                                                        const uint32_t *__restrict__ tile_run_base, uint32_t *__restrict__ dist,
                                                        uint8_t *__restrict__ sym, uint8_t *__restrict__ rank, uint32_t *__restrict__ run_end,
                                                        uint32_t *__restrict__ init, uint32_t *__restrict__ final_last,
                                                        uint32_t *__restrict__ final_lrun) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile[DC_WAVES][DC_PAD + DC_TILE + 16];
+    // 8 KiB of LDS per wave, 32 KiB per workgroup: five workgroups per CU.  The tile has no padding here for that reason (the byte in
+    // front of it is kept in a register).
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[DC_WAVES][DC_TILE];
     __shared__ __attribute__((aligned(16))) uint2 s_pr[DC_WAVES][256];
-    __shared__ unsigned long long s_bm[DC_WAVES][DC_TILE / 64];  // wide tiles: bit j = position j of the tile is the last occurrence of its symbol
+    // wide tiles: bit j = position (window start + j) is the last occurrence of its symbol so far.  The window is the tile and the
+    // DC_WINDOW positions before it (their marks come from the carry table), so that nearly every previous occurrence is inside it.
+    __shared__ __attribute__((aligned(16))) unsigned long long s_bm[DC_WAVES][DC_BM_WORDS];
     __shared__ uint32_t s_first[DC_WAVES][256];                  // wide tiles: first lane of every symbol of the current chunk (else ~0)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t tile = static_cast<size_t>(blockIdx.x) * DC_WAVES + wave;
@@ -249,18 +260,25 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
     uint2 *pr = s_pr[wave];
     unsigned long long *bm = s_bm[wave];
     uint32_t *first_lane = s_first[wave];
-    bm[lane] = 0;
+    bm[2 * lane] = 0;
+    bm[2 * lane + 1] = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) first_lane[k * 64 + lane] = ~0u;
     bool wide = false;  // wave-uniform, decided at the tile's first chunk
-    stage_tile(L, n, base, s, lane);
+    stage_tile<0>(L, n, base, s, lane);
+    const uint32_t before_tile = base > 0 ? L[base - 1] : 0u;
+    const uint32_t base32 = static_cast<uint32_t>(base);
+    const uint32_t ws = base32 >= DC_WINDOW ? base32 - DC_WINDOW : 0u;  // window start (a multiple of 64)
+    const uint32_t tw0 = (base32 - ws) >> 6;                             // bitmap word of the tile's first chunk
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t cp = carry_last[tile * 256 + k * 64 + lane], cr = carry_lrun[tile * 256 + k * 64 + lane];
         pr[k * 64 + lane] = make_uint2(cp, cr);
+        if (cp > ws) atomicOr(&bm[(cp - 1u - ws) >> 6], 1ull << ((cp - 1u - ws) & 63u));  // last occurrence before the tile, inside the window
     }
     uint32_t r = __builtin_amdgcn_readfirstlane(tile_run_base[tile]);  // index of the next run to start (wave-uniform)
-    const uint32_t base32 = static_cast<uint32_t>(base);
     const uint64_t lt = lanemask_lt(lane), le = lt | (1ull << lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -268,8 +286,8 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
         const int j = chunk * 64 + lane;
         const size_t p = base + j;
         const bool valid = p < n;
-        const uint32_t c = s[DC_PAD + j];
-        const uint32_t pc = s[DC_PAD + j - 1];
+        const uint32_t c = s[j];
+        const uint32_t pc = j ? s[j - 1] : before_tile;
         const bool start = valid && (p == 0 || c != pc);
         const uint64_t S = __ballot(start);
         if (S == 0) {
@@ -279,8 +297,8 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
                 const uint32_t p1 = base32 + static_cast<uint32_t>(j) + 1u;
                 if (wide) {  // the open run's symbol: its mark moves to this chunk's last position
                     const uint32_t old1 = pr[c].x;
-                    if (old1 > base32) bm[(old1 - 1u - base32) >> 6] &= ~(1ull << ((old1 - 1u - base32) & 63u));
-                    bm[chunk] = 1ull << lane;
+                    if (old1 > ws) bm[(old1 - 1u - ws) >> 6] &= ~(1ull << ((old1 - 1u - ws) & 63u));
+                    bm[tw0 + chunk] = 1ull << lane;
                 }
                 pr[c] = make_uint2(p1, r);
             }
@@ -343,6 +361,14 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
         }
         const uint2 tab = pr[c];                                           // table state BEFORE this chunk: {pos+1, run+1}
         const uint4 mine = make_uint4(pr[lane].x, pr[64 + lane].x, pr[128 + lane].x, pr[192 + lane].x);
+        // table entries behind position b: lane l speaks for the symbols l, l+64, l+128, l+192 -- four ballots, or two while no symbol
+        // above 127 has been seen (ASCII text)
+        const bool upper_half_live = __ballot((mine.z | mine.w) != 0) != 0;
+        auto table_after = [&](uint32_t b1) -> uint32_t {
+            uint32_t k = static_cast<uint32_t>(__popcll(__ballot(mine.x > b1)) + __popcll(__ballot(mine.y > b1)));
+            if (upper_half_live) k += static_cast<uint32_t>(__popcll(__ballot(mine.z > b1)) + __popcll(__ballot(mine.w > b1)));
+            return k;
+        };
         const bool isA = start && prevsame >= 0;
         const bool isB = start && prevsame < 0;
         // ---- case A: distinct symbols in lanes (w, lane)
@@ -350,7 +376,8 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
         uint64_t mA = __ballot(isA);
         if (mA == 0) {
         } else if (!wide && __popcll(mA) <= DC_FEW_A) {
-            // few such lanes: one ballot each -- the lanes that are first of their symbol after w, cut to (w, lane)
+            // few such lanes: one ballot each -- the lanes that are first of their symbol after w, cut to (w, lane).  (On wide tiles the
+            // dominance count below is faster even for seven lanes: 60 vector instructions against 7 x 3, but no serial scalar chain.)
             while (mA) {
                 const int bit = __builtin_ctzll(mA);
                 mA &= mA - 1;
@@ -370,45 +397,45 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
         const bool first_here = valid && prevsame < 0;
         uint64_t mB = __ballot(isB);
         if (chunk == 0) wide = __popcll(__ballot(first_here)) > DC_WIDE_B;
-        if (wide && chunk > 0 && __popcll(mB) > DC_WIDE_B) {
-            // Wide tile (large alphabet), previous occurrence b inside the tile: the distinct symbols in (b, chunk start) are the marked
-            // positions of the tile bitmap in that range -- a prefix popcount, two cross-lane fetches -- plus the symbols first seen in
-            // this chunk before the lane whose previous occurrence is not after b (the same short loop as below, but lane-parallel in
-            // the other direction).  Lanes whose previous occurrence lies before the tile take the scalar route.
+        if (wide && __popcll(mB) > DC_WIDE_B) {
+            // Wide tile (large alphabet), previous occurrence b inside the window (the tile and the DC_WINDOW positions before it: on
+            // random bytes all of them): the distinct symbols in (b, chunk start) are the marked positions of the bitmap in that range
+            // -- a prefix popcount and three cross-lane fetches -- plus the symbols first seen in this chunk before the lane whose
+            // previous occurrence is not after b (a dominance count).  Previous occurrences before the window take the scalar route.
             const uint32_t b1 = tab.x;
-            const bool in_tile = b1 > base32;
-            const unsigned long long w = bm[lane];
-            const uint32_t pc = static_cast<uint32_t>(__popcll(w));
-            const uint32_t incl = wave_incl_sum(pc, lane);
+            const bool in_window = b1 > ws;  // previous occurrence inside the window
+            const uint4 w2 = *reinterpret_cast<const uint4 *>(bm + 2 * lane);  // bitmap words 2 lane, 2 lane + 1
+            const uint32_t pc0 = static_cast<uint32_t>(__popc(w2.x) + __popc(w2.y)), pc1 = static_cast<uint32_t>(__popc(w2.z) + __popc(w2.w));
+            const uint32_t incl = wave_incl_sum(pc0 + pc1, lane);
             const uint32_t total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
-            const uint32_t lo = in_tile ? b1 - base32 : 0u;  // tile index of the first position after b
-            const int word = static_cast<int>(lo >> 6);
-            const unsigned long long mw = (static_cast<unsigned long long>(static_cast<uint32_t>(__shfl(static_cast<int>(w >> 32), word, 64))) << 32) |
-                                          static_cast<uint32_t>(__shfl(static_cast<int>(w), word, 64));
-            const uint32_t pw = static_cast<uint32_t>(__shfl(static_cast<int>(incl - pc), word, 64));
-            const uint32_t below = pw + static_cast<uint32_t>(__popcll(mw & ((1ull << (lo & 63u)) - 1ull)));
+            const uint32_t lo = in_window ? b1 - ws : 0u;  // window index of the first position after b
+            const unsigned long long mw = bm[lo >> 6];
+            // marks below that word: those below the pair of words of lane (word / 2), plus that lane's even word for an odd word
+            const int owner = static_cast<int>(lo >> 7);
+            const uint32_t below_pair = static_cast<uint32_t>(__shfl(static_cast<int>(incl - pc0 - pc1), owner, 64));
+            const uint32_t even_word = static_cast<uint32_t>(__shfl(static_cast<int>(pc0), owner, 64));
+            const uint32_t below = below_pair + ((lo & 64u) ? even_word : 0u) + static_cast<uint32_t>(__popcll(mw & ((1ull << (lo & 63u)) - 1ull)));
             uint32_t rk = total - below;
             // + the symbols first seen in this chunk in an EARLIER lane whose own previous occurrence is not after mine (their mark sits
             // at or before b, so the bitmap did not count them).  A dominance count over at most 64 lanes: previous occurrences before
             // the tile (or none) always qualify -- one ballot; the in-tile ones are compared bit-sliced (wave_dominance) instead of by
             // a scalar loop over ~57 lanes.
             {
-                const uint64_t outside = __ballot(first_here && !in_tile);
-                const bool memb = first_here && in_tile;
+                const uint64_t outside = __ballot(first_here && !in_window);
+                const bool memb = first_here && in_window;
                 // my previous occurrence is itself a marked position, so `below` is its place among the marks (1 .. 256): an eight-bit key
                 // that orders the members as their positions do
                 const uint32_t K = memb ? below - 1u : 0u;
                 const uint32_t dom = static_cast<uint32_t>(__popcll(outside & lt)) + wave_dominance<8>(K, __ballot(memb) & lt);
                 rk += dom;
             }
-            if (isB) cnt = in_tile ? rk : 0u;
-            uint64_t slow = __ballot(isB && b1 != 0 && !in_tile);
+            if (isB) cnt = in_window ? rk : 0u;
+            uint64_t slow = __ballot(isB && b1 != 0 && !in_window);
             while (slow) {
                 const int bit = __builtin_ctzll(slow);
                 slow &= slow - 1;
                 const uint32_t sb1 = __builtin_amdgcn_readlane(tab.x, bit);
-                uint32_t srk = static_cast<uint32_t>(__popcll(__ballot(mine.x > sb1)) + __popcll(__ballot(mine.y > sb1)) +
-                                                     __popcll(__ballot(mine.z > sb1)) + __popcll(__ballot(mine.w > sb1)));
+                uint32_t srk = table_after(sb1);
                 srk += static_cast<uint32_t>(__popcll(__ballot(first_here && tab.x <= sb1) & ((1ull << bit) - 1ull)));
                 cnt = write_lane(srk, bit, cnt);
             }
@@ -437,8 +464,7 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
                 const uint32_t b1 = __builtin_amdgcn_readlane(tab.x, bit);
                 uint32_t rk = 0;
                 if (b1) {
-                    rk = static_cast<uint32_t>(__popcll(__ballot(mine.x > b1)) + __popcll(__ballot(mine.y > b1)) +
-                                               __popcll(__ballot(mine.z > b1)) + __popcll(__ballot(mine.w > b1)));
+                    rk = table_after(b1);
                     const uint64_t extra = __ballot(first_here && tab.x <= b1) & ((1ull << bit) - 1ull);
                     rk += static_cast<uint32_t>(__popcll(extra));
                 }
@@ -453,8 +479,8 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
         if (start) {
             const uint32_t i = base32 + static_cast<uint32_t>(j);
             const uint32_t ridx = r0 + starts_before;
-            sym[ridx] = static_cast<uint8_t>(c);
-            if (rank) rank[ridx] = static_cast<uint8_t>(cnt);
+            (sym + r0)[starts_before] = static_cast<uint8_t>(c);  // wave-uniform base + 32-bit lane offset: no per-lane 64-bit address
+            if (rank) (rank + r0)[starts_before] = static_cast<uint8_t>(cnt);
             // previous occurrence b (as b + 1; 0 = none) and the run it closed: lane w of this chunk, or the table's
             const uint32_t b1 = isA ? base32 + static_cast<uint32_t>(chunk * 64 + prevsame) + 1u : tab.x;
             const uint32_t prun = isA ? r0 + starts_upto_w - 1u : tab.y - 1u;
@@ -466,9 +492,9 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
         __builtin_amdgcn_wave_barrier();
         const bool last_here = valid && !__builtin_amdgcn_inverse_ballot_w64(notlast);
         if (wide) {  // marks of the symbols of this chunk move to their last lane here
-            if (last_here && tab.x > base32) atomicAnd(&bm[(tab.x - 1u - base32) >> 6], ~(1ull << ((tab.x - 1u - base32) & 63u)));
+            if (last_here && tab.x > ws) atomicAnd(&bm[(tab.x - 1u - ws) >> 6], ~(1ull << ((tab.x - 1u - ws) & 63u)));
             const uint64_t lm = __ballot(last_here);
-            if (lane == 0) bm[chunk] = lm;
+            if (lane == 0) bm[tw0 + chunk] = lm;
         }
         if (last_here) {
             const uint32_t p1 = base32 + static_cast<uint32_t>(j) + 1u;
