@@ -31,7 +31,9 @@ constexpr int DC_CARRY_BATCH = 8;     // tiles whose table rows a carry thread l
 constexpr uint32_t DC_WINDOW = 4096;  // positions before the tile that the bitmap of a wide tile covers as well
 constexpr int DC_BM_WORDS = (DC_TILE + DC_WINDOW) / 64;
 constexpr int DC_FEW_A = 12;         // case-A lanes per chunk up to which each gets its own ballot instead of the shift loop
-constexpr int DC_WIDE_B = 20;        // first occurrences per chunk above which their ranks are counted lane-parallel
+constexpr int DC_WIDE_B = 20;        // first occurrences per chunk above which (without the bitmap) every lane walks the whole table
+constexpr int DC_MARKS_TILE = 4;     // distinct symbols in a tile above which the tile keeps the bitmap
+constexpr int DC_MARKS_B = 6;        // first occurrences per chunk above which the bitmap route is taken (tiles that keep the bitmap)
 constexpr int DC_FEW_LATER = 16;     // wide tiles: lanes per chunk that are neither the first nor the second of their symbol up to which each finds its predecessor by itself
 
 // Stage one tile into wave-private LDS: s[PAD + j] = L[base + j]; with PAD > 0 also its neighbours L[base-1] and L[base+DC_TILE].
@@ -54,7 +56,7 @@ __device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ L, size_t
 
 __global__ __launch_bounds__(DC_BLOCK) void k_dc_summary(const uint8_t *__restrict__ L, size_t n, size_t ntiles,
                                                           uint32_t *__restrict__ tile_last, uint32_t *__restrict__ tile_lrun,
-                                                          uint32_t *__restrict__ tile_runs) {
+                                                          uint32_t *__restrict__ tile_runs, uint32_t *__restrict__ tile_syms) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[DC_WAVES][DC_PAD + DC_TILE + 16];
     __shared__ uint32_t s_last[DC_WAVES][256];
     __shared__ uint32_t s_lrun[DC_WAVES][256];
@@ -87,11 +89,17 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_summary(const uint8_t *__restri
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    uint32_t distinct = 0;
     for (int k = 0; k < 4; ++k) {
-        tile_last[tile * 256 + k * 64 + lane] = s_last[wave][k * 64 + lane];
+        const uint32_t last = s_last[wave][k * 64 + lane];
+        tile_last[tile * 256 + k * 64 + lane] = last;
         tile_lrun[tile * 256 + k * 64 + lane] = s_lrun[wave][k * 64 + lane];
+        distinct += static_cast<uint32_t>(__popcll(__ballot(last != 0)));
     }
-    if (lane == 0) tile_runs[tile] = runs;
+    if (lane == 0) {
+        tile_runs[tile] = runs;
+        tile_syms[tile] = distinct;  // distinct symbols of the tile: k_dc_main picks its routes by it
+    }
 }
 
 // one workgroup: exclusive sum over tiles of the run counts; total -> mail[0]
@@ -240,7 +248,8 @@ __device__ __forceinline__ uint32_t write_lane(uint32_t value, int sel, uint32_t
 // of a dozen scalar instructions per lane loses against sixty vector instructions for all lanes at once.
 __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict__ L, size_t n, size_t ntiles,
                                                        const uint32_t *__restrict__ carry_last, const uint32_t *__restrict__ carry_lrun,
-                                                       const uint32_t *__restrict__ tile_run_base, uint32_t *__restrict__ dist,
+                                                       const uint32_t *__restrict__ tile_run_base, const uint32_t *__restrict__ tile_syms,
+                                                       uint32_t *__restrict__ dist,
                                                        uint8_t *__restrict__ sym, uint8_t *__restrict__ rank, uint32_t *__restrict__ run_end,
                                                        uint32_t *__restrict__ init, uint32_t *__restrict__ final_last,
                                                        uint32_t *__restrict__ final_lrun) {
@@ -264,7 +273,12 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
     bm[2 * lane + 1] = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) first_lane[k * 64 + lane] = ~0u;
-    bool wide = false;  // wave-uniform, decided at the tile's first chunk
+    // wave-uniform: `marks` = the tile has more than DC_MARKS_TILE distinct symbols (k_dc_summary counted them): the bitmap of last
+    // occurrences is kept and serves the chunks with more than DC_MARKS_B first occurrences (text: 0.79 against 1.03 ms for 1e8
+    // bytes; {A,C,G,T} would only pay for keeping it); `wide` = more than DC_WIDE_B distinct symbols in the tile's first chunk: the
+    // symbols of a chunk are matched through the LDS table
+    bool wide = false;
+    const bool marks = __builtin_amdgcn_readfirstlane(tile_syms[tile]) > static_cast<uint32_t>(DC_MARKS_TILE);
     stage_tile<0>(L, n, base, s, lane);
     const uint32_t before_tile = base > 0 ? L[base - 1] : 0u;
     const uint32_t base32 = static_cast<uint32_t>(base);
@@ -295,7 +309,7 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
             // follow its last position in case the run ends exactly at this chunk's end
             if (valid && (lane == 63 || p + 1 == n)) {
                 const uint32_t p1 = base32 + static_cast<uint32_t>(j) + 1u;
-                if (wide) {  // the open run's symbol: its mark moves to this chunk's last position
+                if (marks) {  // the open run's symbol: its mark moves to this chunk's last position
                     const uint32_t old1 = pr[c].x;
                     if (old1 > ws) bm[(old1 - 1u - ws) >> 6] &= ~(1ull << ((old1 - 1u - ws) & 63u));
                     bm[tw0 + chunk] = 1ull << lane;
@@ -397,8 +411,8 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
         const bool first_here = valid && prevsame < 0;
         uint64_t mB = __ballot(isB);
         if (chunk == 0) wide = __popcll(__ballot(first_here)) > DC_WIDE_B;
-        if (wide && __popcll(mB) > DC_WIDE_B) {
-            // Wide tile (large alphabet), previous occurrence b inside the window (the tile and the DC_WINDOW positions before it: on
+        if (marks && __popcll(mB) > DC_MARKS_B) {
+            // Tile that keeps the bitmap, previous occurrence b inside the window (the tile and the DC_WINDOW positions before it: on
             // random bytes all of them): the distinct symbols in (b, chunk start) are the marked positions of the bitmap in that range
             // -- a prefix popcount and three cross-lane fetches -- plus the symbols first seen in this chunk before the lane whose
             // previous occurrence is not after b (a dominance count).  Previous occurrences before the window take the scalar route.
@@ -491,7 +505,7 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
         // ---- table update: the last lane of every symbol of this chunk
         __builtin_amdgcn_wave_barrier();
         const bool last_here = valid && !__builtin_amdgcn_inverse_ballot_w64(notlast);
-        if (wide) {  // marks of the symbols of this chunk move to their last lane here
+        if (marks) {  // marks of the symbols of this chunk move to their last lane here
             if (last_here && tab.x > ws) atomicAnd(&bm[(tab.x - 1u - ws) >> 6], ~(1ull << ((tab.x - 1u - ws) & 63u)));
             const uint64_t lm = __ballot(last_here);
             if (lane == 0) bm[tw0 + chunk] = lm;
@@ -548,14 +562,15 @@ int dc_encode_device(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t init_
     uint32_t *tile_last = ctx->ws_alloc<uint32_t>(ntiles * 256);
     uint32_t *tile_lrun = ctx->ws_alloc<uint32_t>(ntiles * 256);
     uint32_t *tile_runs = ctx->ws_alloc<uint32_t>(ntiles);
+    uint32_t *tile_syms = ctx->ws_alloc<uint32_t>(ntiles);
     uint32_t *chunk_last = ctx->ws_alloc<uint32_t>(nchunks * 256);
     uint32_t *chunk_lrun = ctx->ws_alloc<uint32_t>(nchunks * 256);
     uint32_t *d_init = ctx->ws_alloc<uint32_t>(256);
     uint32_t *d_final = ctx->ws_alloc<uint32_t>(512);
-    if (!tile_last || !tile_lrun || !tile_runs || !chunk_last || !chunk_lrun || !d_init || !d_final) return DK_E_NOMEM;
+    if (!tile_last || !tile_lrun || !tile_runs || !tile_syms || !chunk_last || !chunk_lrun || !d_init || !d_final) return DK_E_NOMEM;
     {
         LaunchScope ls(ctx, K_DC_SUMMARY, 1.0 * n + 2048.0 * ntiles);
-        k_dc_summary<<<dim3(nblocks), dim3(DC_BLOCK), 0, st>>>(d_bwt, n, ntiles, tile_last, tile_lrun, tile_runs);
+        k_dc_summary<<<dim3(nblocks), dim3(DC_BLOCK), 0, st>>>(d_bwt, n, ntiles, tile_last, tile_lrun, tile_runs, tile_syms);
     }
     {
         LaunchScope ls(ctx, K_DC_CARRY, 3.0 * 2048.0 * ntiles);
@@ -567,7 +582,7 @@ int dc_encode_device(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t init_
     }
     {
         LaunchScope ls(ctx, K_DC_MAIN, 1.0 * n + 2048.0 * ntiles);
-        k_dc_main<<<dim3(nblocks), dim3(DC_BLOCK), 0, st>>>(d_bwt, n, ntiles, tile_last, tile_lrun, tile_runs, d_dist, d_sym, d_rank,
+        k_dc_main<<<dim3(nblocks), dim3(DC_BLOCK), 0, st>>>(d_bwt, n, ntiles, tile_last, tile_lrun, tile_runs, tile_syms, d_dist, d_sym, d_rank,
                                                             d_run_end, d_init, d_final, d_final + 256);
     }
     {
