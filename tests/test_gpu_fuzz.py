@@ -17,3 +17,9 @@ def test_randomized_campaign(prefix_mode):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), "10", "5"], env=env, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_dc_stage_campaign():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), "dc", "150", "9"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]

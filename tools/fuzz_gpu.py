@@ -1,6 +1,7 @@
 """One-off randomized campaign on the GPU box: suffix array, BWT + origin, DC arrays and whole-block streams against the oracle, on
 inputs built to cross the thresholds of the suffix sort (prefix probe, text rounds, late rank array, big groups) and of the distance
-coder (narrow / wide tiles, chunks with many first occurrences).  python tools/fuzz_gpu.py [cases] [seed]"""
+coder (narrow / wide tiles, chunks with many first occurrences).  python tools/fuzz_gpu.py [cases] [seed]
+python tools/fuzz_gpu.py dc [cases] [seed]: the DC stage alone on byte arrays of mixed segments (hundreds of cases per minute)."""
 import os
 import sys
 import time
@@ -47,7 +48,51 @@ def make(rng):
     return kind, sigma, np.ascontiguousarray(t)
 
 
+def make_dc_input(rng):
+    """A byte array for the DC stage alone (any byte array is a valid input): segments of different alphabets and run lengths, so
+    that tiles and 64-position chunks of every kind follow each other -- wide / narrow matching, with / without the bitmap, chunks
+    without a run start, previous occurrences inside / before the window."""
+    n = int(rng.integers(1, 40)) if rng.random() < 0.05 else int(rng.integers(100, 1_500_000))
+    parts, total = [], 0
+    while total < n:
+        seg = int(rng.choice([1, 17, 64, 100, 1000, 4096, 5000, 20000, 100000]))
+        sigma = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 16, 21, 22, 40, 64, 100, 128, 129, 200, 256]))
+        lo = int(rng.integers(0, 257 - sigma))
+        mean_run = float(rng.choice([1, 1, 1, 2, 5, 50, 3000]))
+        if mean_run == 1:
+            part = rng.integers(lo, lo + sigma, size=seg)
+        else:
+            lens = rng.geometric(1.0 / mean_run, size=seg // max(1, int(mean_run)) + 2)
+            part = np.repeat(rng.integers(lo, lo + sigma, size=len(lens)), lens)[:seg]
+        if rng.random() < 0.2:  # periodic
+            per = rng.integers(lo, lo + sigma, size=int(rng.integers(1, 70)))
+            part = np.tile(per, seg // len(per) + 1)[:seg]
+        parts.append(part)
+        total += len(part)
+    return np.ascontiguousarray(np.concatenate(parts)[:n], dtype=np.uint8)
+
+
+def main_dc(cases, seed):
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    with dark_amd.Context(2 << 20) as ctx:
+        for c in range(cases):
+            L = make_dc_input(rng)
+            want = orc.dc_encode(L)
+            got = ctx.dc_encode(L)
+            for key in ("init", "d", "sym", "rank"):
+                a, b = np.asarray(got[key]), np.asarray(want[key])
+                if a.shape != b.shape or not (a == b).all():
+                    np.save("gpurun_out/dc_fuzz_fail_%d_%d.npy" % (seed, c), L) if os.path.isdir("gpurun_out") else None
+                    raise AssertionError("dc case %d seed %d n=%d: %s differs" % (c, seed, len(L), key))
+            if c % 50 == 0:
+                print("dc case %d n=%d ok (%.0f s)" % (c, len(L), time.time() - t0), flush=True)
+    print("ok")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "dc":  # python tools/fuzz_gpu.py dc [cases] [seed]: the DC stage alone, many more shapes
+        return main_dc(int(sys.argv[2]) if len(sys.argv) > 2 else 300, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
