@@ -257,10 +257,10 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
     // front of it is kept in a register).
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[DC_WAVES][DC_TILE];
     __shared__ __attribute__((aligned(16))) uint2 s_pr[DC_WAVES][256];
-    // wide tiles: bit j = position (window start + j) is the last occurrence of its symbol so far.  The window is the tile and the
-    // DC_WINDOW positions before it (their marks come from the carry table), so that nearly every previous occurrence is inside it.
+    // tiles that keep the bitmap (`marks`): bit j = position (window start + j) is the last occurrence of its symbol so far.  The window
+    // is the tile and the DC_WINDOW positions before it (their marks come from the carry table): nearly every previous occurrence is inside.
     __shared__ __attribute__((aligned(16))) unsigned long long s_bm[DC_WAVES][DC_BM_WORDS];
-    __shared__ uint32_t s_first[DC_WAVES][256];                  // wide tiles: first lane of every symbol of the current chunk (else ~0)
+    __shared__ uint32_t s_first[DC_WAVES][256];  // `wide` tiles: first lane of every symbol of the current chunk (~0 between chunks)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t tile = static_cast<size_t>(blockIdx.x) * DC_WAVES + wave;
     if (tile >= ntiles) return;
