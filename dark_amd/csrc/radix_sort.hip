@@ -3,12 +3,14 @@
 // sorts and the naming pass become "sort by packed prefix, then by the symbols / ranks further on".
 //
 // Per pass, three phases:
-//   k_radix_hist        per-tile 256-bin digit histograms (LDS atomics over 16 private copies: text digits are skewed)
+//   k_radix_hist        per-tile 256-bin digit histograms (LDS atomics over 16 private copies: text digits are skewed); from the second
+//                       pass on they are counted from the one-byte DIGIT PLANE the previous pass's scatter wrote beside the pairs
+//                       (k_radix_hist_plane: n bytes read instead of 8 n)
 //   k_radix_scan_a/b/c  digit-major exclusive scan of the tile histograms -> global offset of every (tile, digit)
 //   k_radix_scatter     a tile ranks its pairs stably with wave64 ballots (match-any over the 8 digit bits), reorders them in LDS so
 //                       that equal digits are contiguous, then writes runs to HBM.  XCD-aware tile order: every XCD takes one
 //                       contiguous range of tiles, so the short output runs of neighbouring tiles meet in the same L2.
-// Algorithmic bytes per pass: scatter 12 B/pair read + 12 B/pair written; histogram 8 B/key.
+// Algorithmic bytes per pass: scatter 12 B/pair read + 12 (+1: digit plane) B/pair written; histogram 8 B/key, 1 B with the plane.
 // (Two single-kernel-per-pass variants with decoupled look-back -- global ticket order, and per-XCD chunks with the next pass's
 // histograms accumulated while scattering -- were built and measured in round 1: 2.2 TB/s and 1.04 ms per pass of 1e8 pairs against
 // 0.81 ms for these three phases.  They lost and were removed; DESIGN.md section 4.1 keeps the numbers.)
@@ -156,6 +158,40 @@ __global__ __launch_bounds__(RS_BLOCK) void k_radix_hist(const uint64_t *__restr
     }
 }
 
+// The same histograms from the DIGIT PLANE the previous pass's scatter left behind: one byte per pair (the digit this pass sorts by, in
+// the order this pass reads the pairs) instead of the eight bytes of the key -- the histogram pass is a pure streaming read, and seven
+// of its eight bytes were never looked at.
+__global__ __launch_bounds__(RS_BLOCK) void k_radix_hist_plane(const uint8_t *__restrict__ plane, size_t n, uint32_t *__restrict__ tile_hist) {
+    __shared__ uint32_t h[RS_HCOPIES][256];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < RS_HCOPIES * 256; i += RS_BLOCK) (&h[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t *mine = h[tid & (RS_HCOPIES - 1)];
+    const size_t base = static_cast<size_t>(blockIdx.x) * RS_TILE;
+    static_assert(RS_TILE == RS_BLOCK * 16, "one 16-byte load per thread");
+    if (base + RS_TILE <= n && (reinterpret_cast<uintptr_t>(plane) & 15) == 0) {
+        const uint4 v = reinterpret_cast<const uint4 *>(plane + base)[tid];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) atomicAdd(&mine[(w[k] >> (8 * b)) & 0xFFu], 1u);
+        }
+    } else {
+        for (int k = 0; k < 16; ++k) {
+            const size_t i = base + static_cast<size_t>(k) * RS_BLOCK + tid;
+            if (i < n) atomicAdd(&mine[plane[i]], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int c = 0; c < RS_HCOPIES; ++c) sum += h[c][tid];
+        tile_hist[static_cast<size_t>(blockIdx.x) * 256 + tid] = sum;
+    }
+}
+
 // phase A: per chunk of tiles, per digit: sum of the tile counts
 __global__ __launch_bounds__(256) void k_radix_scan_a(const uint32_t *__restrict__ tile_hist, size_t ntiles,
                                                        size_t tiles_per_chunk, uint32_t *__restrict__ chunk_sum) {
@@ -230,7 +266,7 @@ __global__ __launch_bounds__(256) void k_radix_scan_c(uint32_t *__restrict__ til
     }
 }
 
-// tile_offs: the scanned per-tile digit offsets.  xcd_tiles != 0: XCD-aware tile order over a grid of 8 * ceil(ntiles / 8) blocks.
+// tile_offs: the scanned per-tile digit offsets.  next_digit (may be null): the digit plane for the next pass (k_radix_hist_plane).  xcd_tiles != 0: XCD-aware tile order over a grid of 8 * ceil(ntiles / 8) blocks.
 // Three workgroups per CU, not the four that registers and LDS would allow: with a fourth tile in flight per CU the L2 no longer
 // merges the short output runs of neighbouring tiles before it has to evict them (measured, 1e8 text: 3.95 ms of scatter per sort
 // against 3.6 ms; two per CU: 3.65 ms but slower overall).  The kernel is bound by that, not by its ballots: a third fewer vector
@@ -240,7 +276,7 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))
                                                              const uint32_t *__restrict__ pair_lo,
                                                              uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n,
                                                              int shift, const uint32_t *__restrict__ tile_offs, uint32_t xcd_tiles,
-                                                             TextKeys tk) {
+                                                             TextKeys tk, uint8_t *__restrict__ next_digit) {
     __shared__ uint64_t s_keys[RS_TILE];          // tile of keys in digit order; reused for the values
     // per-wave digit counters (then exclusive over waves) | tile-local start of each digit | global offset of the digit minus its
     // tile-local start.  TEXT: the same 6 KiB first hold the staged codes of the tile (the counters are cleared afterwards).
@@ -344,7 +380,10 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))
         const uint32_t p = k * RS_BLOCK + tid;
         const uint64_t kk = s_keys[p];
         gi[k] = s_gbase[digit_of(kk, shift)] + p;
-        if (p < valid) kout[gi[k]] = kk;
+        if (p < valid) {
+            kout[gi[k]] = kk;
+            if (next_digit) next_digit[gi[k]] = static_cast<uint8_t>(digit_of(kk, shift + 8));  // what the next pass's histogram reads
+        }
     }
     if (PAIRS) return;  // keys only
     __syncthreads();
@@ -453,13 +492,21 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
     const size_t mark = ctx->ws_mark();
     uint32_t *tile_hist = ctx->ws_alloc<uint32_t>(ntiles * 256);
     uint32_t *chunk_sum = ctx->ws_alloc<uint32_t>(nchunks * 256);
+    // digit plane: every scatter but the last leaves the next pass's digits behind, one byte per pair (DK_DIGIT_PLANE=0: the
+    // histograms read the keys, as in round 1 -- A/B hook)
+    static const bool plane_enabled = [] { const char *e = getenv("DK_DIGIT_PLANE"); return !(e && e[0] == '0'); }();
+    uint8_t *plane = plane_enabled && end_bit - begin_bit > 8 && count >= (1u << 20) ? ctx->ws_alloc<uint8_t>(count) : nullptr;
     if (!tile_hist || !chunk_sum) return DK_E_NOMEM;
     hipStream_t st = ctx->stream;
     for (int shift = begin_bit; shift < end_bit; shift += 8) {
+        const bool have_plane = plane && shift > begin_bit;      // written by the previous pass
+        uint8_t *emit = plane && shift + 8 < end_bit ? plane : nullptr;  // read by the next one
         {
-            LaunchScope ls(ctx, text && shift == begin_bit ? K_RADIX_HIST_TEXT : K_RADIX_HIST, (text && shift == begin_bit ? 1.0 : 8.0) * count);
+            LaunchScope ls(ctx, text && shift == begin_bit ? K_RADIX_HIST_TEXT : K_RADIX_HIST, (text && shift == begin_bit ? 1.0 : have_plane ? 1.0 : 8.0) * count);
             if (text && shift == begin_bit)
                 k_radix_hist<false, true><<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(nullptr, nullptr, nullptr, count, shift, tile_hist, *text);
+            else if (have_plane)
+                k_radix_hist_plane<<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(plane, count, tile_hist);
             else
                 k_radix_hist<false><<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(keys, nullptr, nullptr, count, shift, tile_hist, TextKeys{});
         }
@@ -474,15 +521,15 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
             }
         }
         {
-            LaunchScope ls(ctx, text && shift == begin_bit ? K_RADIX_SCATTER_TEXT : K_RADIX_SCATTER, (text && shift == begin_bit ? 13.0 : 24.0) * count);
+            LaunchScope ls(ctx, text && shift == begin_bit ? K_RADIX_SCATTER_TEXT : K_RADIX_SCATTER, ((text && shift == begin_bit ? 13.0 : 24.0) + (emit ? 1.0 : 0.0)) * count);
             static const bool xcd = [] { const char *e = getenv("DK_XCD"); return !(e && e[0] == '0'); }();
             const size_t grid = xcd ? 8 * div_up(ntiles, 8) : ntiles;
             if (text && shift == begin_bit)
                 k_radix_scatter<false, true><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(nullptr, nullptr, nullptr, keys_alt, vals_alt, count, shift, tile_hist,
-                                                                                   xcd ? static_cast<uint32_t>(ntiles) : 0u, *text);
+                                                                                   xcd ? static_cast<uint32_t>(ntiles) : 0u, *text, emit);
             else
                 k_radix_scatter<false><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(keys, vals, nullptr, keys_alt, vals_alt, count, shift, tile_hist,
-                                                                             xcd ? static_cast<uint32_t>(ntiles) : 0u, TextKeys{});
+                                                                             xcd ? static_cast<uint32_t>(ntiles) : 0u, TextKeys{}, emit);
         }
         DK_HIP(ctx, hipGetLastError());
         std::swap(keys, keys_alt);
@@ -564,7 +611,7 @@ int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, 
     {
         LaunchScope ls(ctx, K_RADIX_SCATTER, 16.0 * count);
         k_radix_scatter<true><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(nullptr, idx, val, scratch, nullptr, count, shift, tile_hist,
-                                                                       static_cast<uint32_t>(ntiles), TextKeys{});
+                                                                       static_cast<uint32_t>(ntiles), TextKeys{}, nullptr);
     }
     {
         LaunchScope ls(ctx, K_BUCKET_STORE, 12.0 * count);
