@@ -1,6 +1,6 @@
 """Alternative code paths selected by environment variables (read once per process, hence subprocesses):
 DK_ENTROPY_THREADS=2|4 (models | coder on two host threads, the four-stage pipeline of the dark model),
-DK_BUCKETED=0 / DK_XCD=0 / DK_DIGIT_PLANE=0 (plain rank scatter / plain tile order / histograms from the keys), DK_PLATEAU=0 (general doubling rounds only, no in-place rounds),
+DK_BUCKETED=0 / DK_XCD=0 / DK_DIGIT_PLANE=1 (plain rank scatter / plain tile order / histograms from the digit plane at every size), DK_PLATEAU=0 (general doubling rounds only, no in-place rounds),
 DK_BWT_CARRY=0 (L gathered from the suffix array instead of riding with the suffixes), DK_RANKS_FIRST=1 (rank array built straight after
 the initial sort, first round a doubling round, instead of text-extension rounds first).  Every variant must give the same bytes."""
 import os
@@ -138,7 +138,7 @@ def test_entropy_error_paths_return_codes(threads):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"DK_BUCKETED": "0"}, {"DK_XCD": "0"}, {"DK_DIGIT_PLANE": "0"},
+@pytest.mark.parametrize("env", [{"DK_BUCKETED": "0"}, {"DK_XCD": "0"}, {"DK_DIGIT_PLANE": "1"},
                                  {"DK_PLATEAU": "0"}, {"DK_BWT_CARRY": "0"}, {"DK_PLATEAU": "0", "DK_BWT_CARRY": "0"}, {"DK_RANKS_FIRST": "1"}, {"DK_PACK": "1"},
                                  {"DK_RANKS_FIRST": "1", "DK_BUCKETED": "0", "DK_PLATEAU": "0"}])
 def test_gpu_variants_match_oracle(env):
