@@ -58,19 +58,20 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_summary(const uint8_t *__restri
                                                           uint32_t *__restrict__ tile_last, uint32_t *__restrict__ tile_lrun,
                                                           uint32_t *__restrict__ tile_runs, uint32_t *__restrict__ tile_syms) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[DC_WAVES][DC_PAD + DC_TILE + 16];
+    // per symbol: (last position inside the tile + 1) << 13 | run index inside the tile + 1 -- both are at most DC_TILE and grow
+    // together, so ONE LDS max per run end keeps the pair
     __shared__ uint32_t s_last[DC_WAVES][256];
-    __shared__ uint32_t s_lrun[DC_WAVES][256];
+    static_assert(DC_TILE <= 4096, "position and run index share a 32-bit word, 13 bits each");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t tile = static_cast<size_t>(blockIdx.x) * DC_WAVES + wave;
     if (tile >= ntiles) return;  // whole wave leaves together; no workgroup barrier below
     const size_t base = tile * DC_TILE;
     uint8_t *s = s_tile[wave];
-    for (int k = 0; k < 4; ++k) { s_last[wave][k * 64 + lane] = 0; s_lrun[wave][k * 64 + lane] = 0; }
+    for (int k = 0; k < 4; ++k) s_last[wave][k * 64 + lane] = 0;
     stage_tile<DC_PAD>(L, n, base, s, lane);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     uint32_t runs = 0;
-    const uint64_t le = lanemask_lt(lane) | (1ull << lane);
     for (int chunk = 0; chunk < DC_TILE / 64; ++chunk) {
         const int j = chunk * 64 + lane;
         const size_t p = base + j;
@@ -78,23 +79,21 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_summary(const uint8_t *__restri
         const uint32_t c = s[DC_PAD + j];
         const bool start = valid && (p == 0 || c != s[DC_PAD + j - 1]);
         const uint64_t m = __ballot(start);
-        const uint32_t incl = runs + static_cast<uint32_t>(__popcll(m & le));
+        // run starts up to and including this lane (v_mbcnt counts the lanes below)
+        const uint32_t incl = runs + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)) + (start ? 1u : 0u);
         // only the last position of a run inside the tile can be the tile's last occurrence of its symbol
         const bool is_end = valid && (p + 1 >= n || j == DC_TILE - 1 || s[DC_PAD + j + 1] != c);
-        if (is_end) {
-            atomicMax(&s_last[wave][c], static_cast<uint32_t>(p + 1));
-            atomicMax(&s_lrun[wave][c], incl);
-        }
+        if (is_end) atomicMax(&s_last[wave][c], (static_cast<uint32_t>(j + 1) << 13) | incl);
         runs += static_cast<uint32_t>(__popcll(m));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     uint32_t distinct = 0;
     for (int k = 0; k < 4; ++k) {
-        const uint32_t last = s_last[wave][k * 64 + lane];
-        tile_last[tile * 256 + k * 64 + lane] = last;
-        tile_lrun[tile * 256 + k * 64 + lane] = s_lrun[wave][k * 64 + lane];
-        distinct += static_cast<uint32_t>(__popcll(__ballot(last != 0)));
+        const uint32_t packed = s_last[wave][k * 64 + lane];
+        tile_last[tile * 256 + k * 64 + lane] = packed ? static_cast<uint32_t>(base) + (packed >> 13) : 0u;  // position + 1
+        tile_lrun[tile * 256 + k * 64 + lane] = packed & 0x1FFFu;
+        distinct += static_cast<uint32_t>(__popcll(__ballot(packed != 0)));
     }
     if (lane == 0) {
         tile_runs[tile] = runs;
