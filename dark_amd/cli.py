@@ -56,6 +56,54 @@ class Refused(SystemExit):
     pass
 
 
+class _AtomicOutput:
+    """The archive is written to a temporary file next to its final name and renamed over it only when it is complete (records and
+    footer written, file closed): a refusal, a GPU error or a failed worker leaves an existing archive of that name untouched and never
+    leaves a truncated one behind -- a footer-less prefix of records would otherwise decode as a valid, shorter file."""
+
+    def __init__(self, out_path):
+        self.final = out_path
+        self.tmp = os.path.join(os.path.dirname(out_path) or ".", ".%s.tmp%d" % (os.path.basename(out_path), os.getpid()))
+        self.f = None
+
+    def __enter__(self):
+        self.f = open(self.tmp, "wb")
+        return self.f
+
+    def __exit__(self, exc_type, exc, tb):
+        self.f.close()
+        if exc_type is None:
+            os.replace(self.tmp, self.final)
+        else:
+            try:
+                os.remove(self.tmp)
+            except OSError:
+                pass
+        return False
+
+
+_NOTED = set()
+
+
+def _note(key, text):
+    """one line on stderr, once per run"""
+    if key not in _NOTED:
+        _NOTED.add(key)
+        print("dark_amd: " + text, file=sys.stderr)
+
+
+def _note_model(model):
+    if model in RAW_CODING_MODELS:
+        _note("bbb", "-m bbb is EXPERIMENTAL here: the model's gates restate compress::entropy::ari::apm from an in-repo analogue (parity "
+                     "unpinned, DESIGN.md section 7); archives decode with this program, compatibility with the Rust crate's bytes is not claimed")
+
+
+def _note_single_symbol(block, where):
+    if len(block) and int(block.min()) == int(block.max()):
+        _note("single", "%s holds one distinct byte value: this program decodes it, the reference's decoder mis-reads `origin` for such a "
+                        "block and returns one byte (DESIGN.md, reference quirks)" % where)
+
+
 def _check_ff(block, force, where):
     if not force and bool((block == 255).any()):
         raise Refused("%s contains byte 0xFF: the reference format cannot carry that symbol (src/block/dc.rs:57-73), the archive could "
@@ -69,7 +117,10 @@ def _encode_single(path, model, device, force, out_path):
     n = len(data)
     if n == 0:
         raise SystemExit("empty input: the reference panics on it (src/saca.rs:107)")
-    with Context(n, device) as ctx, open(out_path, "wb") as out:
+    if model not in DUMP_MODELS and model not in RAW_CODING_MODELS:
+        _check_ff(data, force, "the block")               # before the output is touched
+    _note_single_symbol(data, "the input")
+    with Context(n, device) as ctx, _AtomicOutput(out_path) as out:
         out.write(struct.pack("<I", n))                   # main.rs:102
         _write_block(ctx, model, data, out, True, force)
     return out_path
@@ -104,6 +155,7 @@ def _reader(f, block_size, first_block, step, total_blocks, q, force, device):
             f.seek(b * block_size)
             block = np.fromfile(f, dtype=np.uint8, count=block_size)  # ONE block of input in host memory
             _check_ff(block, force, "block %d" % b)
+            _note_single_symbol(block, "block %d" % b)
             q.put((b, len(block), torch.from_numpy(block).to("cuda:%d" % device)))
             del block
         q.put(None)
@@ -137,26 +189,25 @@ def _encode_blocks(path, model, block_size, device, first_block, step, total_blo
                 index.append((b, 4 + len(s)))
             batch, pending = None, []
 
-        while True:
-            item = q.get()
-            if item is None:
-                break
-            if isinstance(item, BaseException):
-                if batch is not None:
-                    try:
-                        batch.finish()
-                    except Exception:  # noqa: BLE001 -- the reader's error is the one to report
-                        pass
-                raise item
-            b, n, d = item
-            if batch is None:
-                batch = ctx.batch_begin(model, host_threads)
-            batch.push(d, n)
-            pending.append((b, n))
-            del d, item
-            if len(pending) >= flush_every:
-                flush()
-        flush()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                b, n, d = item
+                if batch is None:
+                    batch = ctx.batch_begin(model, host_threads)
+                batch.push(d, n)  # a failed push closes the batch (joins the coders of the blocks before it) and raises
+                pending.append((b, n))
+                del d, item
+                if len(pending) >= flush_every:
+                    flush()
+            flush()
+        finally:
+            if batch is not None:
+                batch.close()  # error path: the coding threads are joined before their output buffers and the context go away
         t.join()
 
 
@@ -216,21 +267,23 @@ def encode_file(path, model, block_size=0, device=0, gpus=1, force=False, host_t
     total = os.path.getsize(path)
     if total == 0:
         raise SystemExit("empty input: the reference panics on it (src/saca.rs:107)")
+    _note_model(model)
     if not block_size or block_size >= total:
         return _encode_single(path, model, device, force, out_path)
     nblocks = -(-total // block_size)
     if model in DUMP_MODELS or model in RAW_CODING_MODELS:  # block after block through the host entry points
         from .context import Context
-        with open(path, "rb") as f, Context(block_size, device) as ctx, open(out_path, "wb") as out:
+        with open(path, "rb") as f, Context(block_size, device) as ctx, _AtomicOutput(out_path) as out:
             for b in range(nblocks):
                 block = np.fromfile(f, dtype=np.uint8, count=block_size)
+                _note_single_symbol(block, "block %d" % b)
                 out.write(struct.pack("<I", len(block)))
                 _write_block(ctx, model, block, out, b == 0, force)
         return out_path
     threads = host_threads or max(1, _host_threads() // max(1, gpus) - 1)
     if gpus <= 1:
         index = []
-        with open(out_path, "wb") as out:
+        with _AtomicOutput(out_path) as out:
             _encode_blocks(path, model, block_size, device, 0, 1, nblocks, out, index, force, threads)
             offsets, pos = [], 0
             for _, ln in index:
@@ -261,7 +314,7 @@ def encode_file(path, model, block_size=0, device=0, gpus=1, force=False, host_t
     lens = [[int(x) for x in open(part + ".idx").read().split()] for part in parts]
     files = [open(part, "rb") for part in parts]
     offsets, pos = [], 0
-    with open(out_path, "wb") as out:
+    with _AtomicOutput(out_path) as out:
         for b in range(nblocks):
             r, k = b % gpus, b // gpus
             ln = lens[r][k]
@@ -355,7 +408,7 @@ def decode_file(path, model, device=0, gpus=1, host_threads=0, devices=None):
         size = os.path.getsize(path)
         with open(path, "rb") as f, open(out_path, "wb") as out:
             blob = np.fromfile(f, dtype=np.uint8)
-            pos, ctx = 0, None
+            pos, ctx, records = 0, None, 0
             while pos < size:
                 if pos + 4 > size:
                     raise SystemExit("truncated record header at byte %d" % pos)
@@ -370,8 +423,12 @@ def decode_file(path, model, device=0, gpus=1, host_threads=0, devices=None):
                 else:
                     out.write(ctx.block_decode(model, blob[pos:], n))
                 pos += ctx.last_consumed()
+                records += 1
             if ctx is not None:
                 ctx.close()
+        if records > 1:
+            _note("walked", "%d records without an index footer: every record decoded, but a file cut off at a record boundary cannot be "
+                            "told from a complete one (archives written by -b carry a footer; bbb archives and plain concatenations do not)" % records)
         return out_path
     offsets, end = footer
     if gpus <= 1:

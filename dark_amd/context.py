@@ -54,10 +54,14 @@ class Context:
         if rc != 0:
             raise DarkError(rc, "dk_ctx_create(device=%d, max_n=%d)" % (device, max_n))
         self._h = h
+        self._batch = None  # the streaming Batch open on this context, if any
         self.device = device
 
     def close(self):
         if getattr(self, "_h", None):
+            b = getattr(self, "_batch", None)
+            if b is not None:
+                b.close()  # joins its coding threads before the staging memory goes (dk_ctx_destroy would do the same)
             self._lib.dk_ctx_destroy(self._h)
             self._h = None
 
@@ -263,26 +267,59 @@ class Context:
 
 
 class Batch:
-    """dk_batch_begin / _push / _finish: the pipelined encoder fed one block at a time"""
+    """dk_batch_begin / _push / _finish: the pipelined encoder fed one block at a time.
+
+    The C coding threads write into this object's `out` buffers and length words until dk_batch_finish has joined them, so finish
+    ALWAYS runs before those buffers or the context can go away: on a failed push (the error is raised after the batch is closed), at
+    the end of a `with` block, from Context.close(), and as a last resort from __del__."""
 
     def __init__(self, ctx, model, host_threads):
         self._ctx = ctx
         self._h = C.c_void_p()
-        ctx._ck(ctx._lib.dk_batch_begin(ctx._h, model_id(model), int(host_threads), C.byref(self._h)))
         self._outs, self._lens = [], []
+        ctx._ck(ctx._lib.dk_batch_begin(ctx._h, model_id(model), int(host_threads), C.byref(self._h)))
+        ctx._batch = self
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def push(self, d_in, n):
         """device stages of one block now (d_in may be reused when this returns), coding in the background"""
+        if not self._h:
+            raise DarkError(_lib.DK_E_ARG, "the batch is closed")
         _inputs_ready(d_in)
         out = np.empty(2 * int(n) + 4096, dtype=np.uint8)  # virtual until written: only the coded bytes become resident
         ln = C.c_size_t(0)
         self._outs.append(out)
         self._lens.append(ln)
-        self._ctx._ck(self._ctx._lib.dk_batch_push(self._h, _ptr(d_in), int(n), _ptr(out), len(out), C.byref(ln)))
+        rc = self._ctx._lib.dk_batch_push(self._h, _ptr(d_in), int(n), _ptr(out), len(out), C.byref(ln))
+        if rc != 0:
+            text = (self._ctx._lib.dk_last_error(self._ctx._h) or b"").decode()
+            self.close()  # joins the coders of the blocks already queued; only then may the buffers die with this object
+            raise DarkError(rc, text)
+
+    def close(self):
+        """dk_batch_finish without collecting anything (idempotent); returns its code"""
+        h, self._h = self._h, None
+        if not h:
+            return 0
+        if getattr(self._ctx, "_batch", None) is self:
+            self._ctx._batch = None
+        return self._ctx._lib.dk_batch_finish(h)
 
     def finish(self):
-        h, self._h = self._h, None
-        self._ctx._ck(self._ctx._lib.dk_batch_finish(h))
+        if not self._h:
+            raise DarkError(_lib.DK_E_ARG, "the batch is closed")
+        self._ctx._ck(self.close())
         return [o[:ln.value] for o, ln in zip(self._outs, self._lens)]
 
 

@@ -18,6 +18,9 @@ namespace {
 
 int begin_call(dk_ctx *ctx) {
     if (!ctx) return DK_E_ARG;
+    // a streaming batch owns the workspace and the staging slots until it is finished: any other call would pull them from under
+    // the coding threads
+    if (ctx->live_batch) return ctx->fail(DK_E_ARG, "a streaming batch is open on this context: call dk_batch_finish first");
     ctx->err.clear();
     ctx->last_flags = 0;
     ctx->ws_reset();
@@ -33,9 +36,19 @@ int check_n(dk_ctx *ctx, size_t n) {
     return DK_OK;
 }
 size_t workspace_bytes(size_t max_n) {
-    // text copy n + L n + SA 4 n + suffix-sort temporaries 62 n + per-tile tables (< n) + slack; the DC arrays (10 n) and the
-    // inverse BWT's successor table (8 n) reuse the temporaries' place
-    return 70 * max_n + (48u << 20);
+    // Peak of the bump allocator, reached inside the suffix sort of a host-pointer block call (every term is one ws_alloc of the call):
+    //   text copy                                   n     (host entry points only)
+    //   L                                           n
+    //   SA                                         4 n
+    //   suffix sort: keys x3 24 n, suffix lists x3 12 n, rank 4 n, slot positions x2 8 n, group ids x2 8 n,
+    //                gstart + bigstart 4 n, symbols in front x2 2 n                                  = 62 n
+    //   radix sort inside it: per-tile digit tables n / 4 (256 counters per 4096 pairs), digit plane n (optional, >= 2^28 pairs:
+    //                ws_try_alloc -- the sort runs without it when it does not fit)
+    //   rerank / classification aggregates         < n / 64
+    // = 69.3 n; every allocation is rounded up to 256 bytes (about forty of them: < 16 KiB).  The DC arrays (10 n) and the inverse
+    // BWT's successor table (8 n) are allocated after the sort's temporaries are released and take their place.
+    const size_t sort_temporaries = 62 * max_n, io = 6 * max_n, tables = max_n / 4 + max_n / 64, plane = max_n;
+    return sort_temporaries + io + tables + plane + max_n / 2 /* headroom */ + (48u << 20);
 }
 struct ScopedCall {
     dk_ctx *c;
@@ -192,6 +205,9 @@ int dk_ctx_create(int hip_device, size_t max_n, dk_ctx **out) {
 
 void dk_ctx_destroy(dk_ctx *c) {
     if (!c) return;
+    // a batch left open (an error path that never reached dk_batch_finish): its coding threads still read the pinned staging slots
+    // freed below -- join them first
+    if (c->live_batch) (void)dk_batch_finish(c->live_batch);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -341,6 +357,7 @@ int dk_batch_begin(dk_ctx *ctx, int model_id, int host_threads, dk_batch **out) 
     const size_t workers = static_cast<size_t>(std::max(1, host_threads));
     for (size_t k = 0; k < workers + 1; ++k) b->free_slots.push_back(static_cast<int>(k));
     for (size_t w = 0; w < workers; ++w) b->pool.emplace_back([b] { b->worker(); });
+    ctx->live_batch = b;
     *out = b;
     return DK_OK;
 }
@@ -387,6 +404,7 @@ int dk_batch_finish(dk_batch *b) {
     }
     b->cv_job.notify_all();
     for (auto &th : b->pool) th.join();
+    b->ctx->live_batch = nullptr;
     int rc = b->first_rc;
     if (rc != DK_OK) rc = b->ctx->fail(rc, "entropy stage of block %zu failed (%d)", b->first_bad, rc);
     delete b;

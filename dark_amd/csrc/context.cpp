@@ -28,6 +28,15 @@ int dk_ctx::fail(int code, const char *fmt, ...) {
     return code;
 }
 
+void *dk_ctx::ws_try_alloc_bytes(size_t bytes) {
+    const size_t aligned = (bytes + 255) & ~static_cast<size_t>(255);
+    if (ws_used + aligned > ws_size) return nullptr;
+    void *p = ws + ws_used;
+    ws_used += aligned;
+    if (ws_used > ws_peak) ws_peak = ws_used;
+    return p;
+}
+
 void *dk_ctx::ws_alloc_bytes(size_t bytes) {
     const size_t aligned = (bytes + 255) & ~static_cast<size_t>(255);
     if (ws_used + aligned > ws_size) {

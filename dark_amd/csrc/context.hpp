@@ -76,6 +76,7 @@ struct dk_ctx {
     std::vector<StageSlot> slots;
     int ensure_slot(size_t index, size_t bytes);
     std::string err;
+    struct dk_batch *live_batch = nullptr;  // the streaming batch open on this context (dk_batch_begin .. dk_batch_finish), if any
     unsigned last_flags = 0;   // DK_FLAG_* of the block the last block encode coded
     size_t last_consumed = 0;  // bytes of coded stream the last block decode read (records can be concatenated)
     dk_stats stats{};
@@ -92,6 +93,9 @@ struct dk_ctx {
     // 256-byte aligned bump allocation; returns nullptr (and records the error) when the workspace is exhausted
     void *ws_alloc_bytes(size_t bytes);
     template <class T> T *ws_alloc(size_t count) { return static_cast<T *>(ws_alloc_bytes(count * sizeof(T))); }
+    // the same for OPTIONAL buffers (a faster variant that can be done without): nullptr when it does not fit, no error recorded
+    void *ws_try_alloc_bytes(size_t bytes);
+    template <class T> T *ws_try_alloc(size_t count) { return static_cast<T *>(ws_try_alloc_bytes(count * sizeof(T))); }
     size_t ws_mark() const { return ws_used; }
     void ws_release(size_t mark) { ws_used = mark; }
 

@@ -498,7 +498,7 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
     // DK_DIGIT_PLANE=1 / 0: always (from 2^20 pairs) / never.
     static const int plane_mode = [] { const char *e = getenv("DK_DIGIT_PLANE"); return e ? atoi(e) : -1; }();
     const size_t plane_from = plane_mode == 1 ? (size_t(1) << 20) : (size_t(1) << 28);
-    uint8_t *plane = plane_mode != 0 && end_bit - begin_bit > 8 && count >= plane_from ? ctx->ws_alloc<uint8_t>(count) : nullptr;
+    uint8_t *plane = plane_mode != 0 && end_bit - begin_bit > 8 && count >= plane_from ? ctx->ws_try_alloc<uint8_t>(count) : nullptr;  // optional: the sort runs without it
     if (!tile_hist || !chunk_sum) return DK_E_NOMEM;
     hipStream_t st = ctx->stream;
     for (int shift = begin_bit; shift < end_bit; shift += 8) {

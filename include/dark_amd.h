@@ -125,7 +125,10 @@ int dk_dev_batch_encode(dk_ctx *ctx, int model_id, size_t count, const uint8_t *
 /* The same pipeline fed one block at a time (blocks that arrive from a file): begin starts `host_threads` coding threads;
  * push runs the device stages of one more block on the calling thread -- on return d_in may be reused -- and queues its coding
  * (it waits while every staging slot is busy); *out_len is written when that block's coding ends; finish waits for all coders,
- * frees the batch and returns the first failure.  Between begin and finish the context serves this batch only. */
+ * frees the batch and returns the first failure.  Between begin and finish the context serves this batch only: every other entry point
+ * returns DK_E_ARG, a second begin included.  A failed push leaves the batch open (earlier blocks are still being coded into the
+ * caller's `out` / `out_len`): the caller must still call finish before it frees those buffers.  dk_ctx_destroy finishes a batch that
+ * was left open, so the coding threads never outlive the staging memory they read. */
 typedef struct dk_batch dk_batch;
 int dk_batch_begin(dk_ctx *ctx, int model_id, int host_threads, dk_batch **out);
 int dk_batch_push(dk_batch *batch, const uint8_t *d_in, size_t n, uint8_t *out, size_t out_cap, size_t *out_len);

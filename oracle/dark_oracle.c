@@ -1139,10 +1139,13 @@ int orc_bitcoder_decode(const uint8_t *in, size_t in_len, const uint16_t *flat, 
  *   G5  Bit::predict() is "flat >= 2048" (bbb.rs:268-274 then mirrors main.cpp:542 `p+=p<2048`)
  * None of G2-G5 can be checked in this image; a stream made here round-trips here and nowhere else is claimed.
  * ============================================================================================== */
-static const uint8_t BBB_STATE_FLAT[256 * 4] = {
-#include "../dark_amd/csrc/bbb_states.inc"
+/* the oracle's OWN copy of the state table, generated from the reference's literal by oracle/make_bbb_table.py (the product keeps a
+ * separate one, dark_amd/csrc/bbb_states.inc; tests/test_oracle.py compares both with src/model/bbb.rs:34-99) */
+static const uint8_t BBB_STATE_ROWS[256][4] = {
+#include "bbb_state_table.inc"
 };
-#define BBB_STATE(state, col) BBB_STATE_FLAT[(state) * 4 + (col)]
+#define BBB_STATE(state, col) BBB_STATE_ROWS[(state)][(col)]
+const uint8_t *orc_bbb_state_table(void) { return &BBB_STATE_ROWS[0][0]; }
 
 static int bbb_squash(int d) { /* etc/bbb/main.cpp:348-359 */
     static const int t[33] = {1, 2, 3, 6, 10, 16, 27, 45, 73, 120, 194, 310, 488, 747, 1101, 1546, 2047, 2549, 2994, 3348, 3607, 3785, 3901,

@@ -67,6 +67,8 @@ int orc_raw_bbb_encode_bwt(const uint8_t *bwt, size_t n, uint32_t origin, uint8_
 int orc_raw_bbb_decode_bwt(const uint8_t *in, size_t in_len, size_t n, uint8_t *bwt, uint32_t *origin);
 
 /* stage timers of the last orc_block_dc_encode call on this thread (seconds): sa, bwt, dc, entropy */
+/* the 256 x 4 bit-history state table the bbb model above was compiled with (oracle/bbb_state_table.inc) */
+const uint8_t *orc_bbb_state_table(void);
 void orc_last_stage_seconds(double out[4]);
 
 #ifdef __cplusplus

@@ -18,7 +18,7 @@ MODEL_IDS = {"dark": 0, "exp": 1, "ybs": 2, "simple": 3, "rawdc": 4}
 
 def build(force=False):
     """Compile the oracle with gcc (plain C, no GPU)."""
-    srcs = [os.path.join(_HERE, f) for f in ("dark_oracle.c", "dark_oracle.h", "sais_body.inc", "../dark_amd/csrc/bbb_states.inc")]
+    srcs = [os.path.join(_HERE, f) for f in ("dark_oracle.c", "dark_oracle.h", "sais_body.inc", "bbb_state_table.inc")]
     if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs):
         return _SO
     subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -51,6 +51,8 @@ def lib():
         L.orc_bitcoder_decode.argtypes = [u8p, C.c_size_t, u16p, C.c_size_t, u8p]
         L.orc_raw_bbb_encode_bwt.argtypes = [u8p, C.c_size_t, C.c_uint32, u8p, C.c_size_t, szp]
         L.orc_raw_bbb_decode_bwt.argtypes = [u8p, C.c_size_t, C.c_size_t, u8p, C.POINTER(C.c_uint32)]
+        L.orc_bbb_state_table.restype = C.POINTER(C.c_uint8 * 1024)
+        L.orc_bbb_state_table.argtypes = []
         L.orc_last_stage_seconds.argtypes = [C.POINTER(C.c_double * 4)]
         L.orc_last_stage_seconds.restype = None
         _lib = L
@@ -221,6 +223,11 @@ def raw_bbb_decode(stream, n):
     origin = C.c_uint32(0)
     _ck(lib().orc_raw_bbb_decode_bwt(_p(s), len(s), n, _p(bwt), C.byref(origin)), "orc_raw_bbb_decode_bwt")
     return bwt_inverse(bwt, int(origin.value)).tobytes()
+
+
+def bbb_state_table():
+    """the 256 x 4 bit-history state table the oracle's bbb model was compiled with"""
+    return np.frombuffer(lib().orc_bbb_state_table().contents, dtype=np.uint8).reshape(256, 4).copy()
 
 
 def last_stage_seconds():

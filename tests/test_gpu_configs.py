@@ -1,12 +1,12 @@
 """Every BASELINE.json config through the GPU path against the CPU oracle, inside the -m gpu suite (VERDICT r1 "What's missing" 1):
 
   configs[0]  book1 (768 771 B)        -> book1_like_768771: stage by stage + the coded streams of all four models
-  configs[1]  enwik8 (1e8, one block)  -> enwik8_like_1e8: the coded stream equals the oracle's, byte for byte
-  configs[3]  enwik9 as 125e6 blocks   -> one enwik9_block_125e6 block: stream equals the oracle's + round trip
+  configs[1]..[4] at their full sizes (1e8 text, 2^28 ACGT, 125e6 text, 2^30 random bytes) are in test_gpu_fullsize.py: every stage
+              against the oracle, byte for byte
   A17 (src/entropy/{mod,ari}.rs) and the model level (src/model/mod.rs:59-76) on the GPU box's build of the library
   the reference's one external number (README.md:20, book1 -> 214 445 B with -m dark) when a real corpus is supplied
 
-The full-size property checks (SA / BWT / DC round trips, 2^28 ACGT, 2^30 random) are in test_gpu_fullsize.py."""
+"""
 import os
 import subprocess
 import sys
@@ -17,7 +17,7 @@ import pytest
 import dark_amd
 from dark_amd import datagen
 from conftest import ROOT
-from test_gpu_parity import check_all_stages, first_diff
+from test_gpu_parity import check_all_stages
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -31,30 +31,6 @@ def test_config0_book1_like_all_stages_all_models(orc):
         check_all_stages(ctx, orc, t, models=MODELS)
         # the rawdc dump (src/model/raw.rs:12-44) at this size as well: one 10-byte record per model.encode call
         assert ctx.block_encode("rawdc", t) == orc.block_dc_encode("rawdc", t)
-
-
-@pytest.mark.parametrize("workload,n,seed", [("enwik8_like_1e8", 100_000_000, 2), ("enwik9_block_125e6", 125_000_000, 40)])
-def test_fullsize_stream_equals_oracle(orc, workload, n, seed):
-    """BASELINE configs[1] / configs[3]: "bit-exact check vs CPU output" at the full block size.  The oracle needs 15-20 s per block."""
-    block = datagen.wiki_like(n, seed)
-    d_in = torch.from_numpy(block).cuda()
-    with dark_amd.Context(n) as ctx:
-        stream = ctx.dev_block_encode("dark", d_in, n).copy()
-        st = ctx.stats()
-        # one SA-IS run of the oracle serves both checks: the BWT stage boundary and the coded stream
-        want_bwt, want_origin = orc.bwt_forward(block)
-        want = orc.block_dc_encode_bwt("dark", want_bwt, want_origin)
-        assert len(stream) == len(want) and stream.tobytes() == want, (workload, len(stream), len(want))
-        d_bwt = torch.empty(n, dtype=torch.uint8, device="cuda")
-        origin = ctx.dev_bwt_forward(d_in, n, d_bwt)
-        assert origin == want_origin
-        assert first_diff(d_bwt.cpu().numpy(), want_bwt) is None
-        del want_bwt, d_bwt
-        if workload == "enwik9_block_125e6":  # the 1e8 round trip is in test_gpu_fullsize.py
-            d_out = torch.empty(n, dtype=torch.uint8, device="cuda")
-            ctx.dev_block_decode("dark", stream, n, d_out)
-            assert torch.equal(d_out, d_in)
-        print(workload, "stream", len(stream), "rounds", st["rounds"], "sa ms", round(st["ms_sa"], 2), "entropy ms", round(st["ms_entropy"], 1))
 
 
 def test_a17_bitcoder_and_model_level(orc, vectors):

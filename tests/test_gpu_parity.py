@@ -262,6 +262,54 @@ def test_cli_constant_blocks_and_0xff(tmp_path, license_bytes, monkeypatch):
         cli.decode_file(out, "dark")
 
 
+def test_cli_refusal_and_failure_leave_no_damage(tmp_path, license_bytes, monkeypatch):
+    """the archive is written to a temporary file and renamed only when complete.  A refusal (byte 0xFF, with or without -b) or
+    a failure mid-file must leave an existing good archive of the same name untouched, and no partial file behind."""
+    import os
+    from dark_amd import cli
+    monkeypatch.chdir(tmp_path)
+    good = license_bytes * 12
+    (tmp_path / "data.txt").write_bytes(good)
+    out = cli.encode_file(str(tmp_path / "data.txt"), "dark", 5000)
+    before = open(out, "rb").read()
+    (tmp_path / "data.bin").write_bytes(good + b"\xff" + good)  # same stem -> same archive name; 0xFF sits in block 2 of 3
+    for bs in (0, len(good) // 2 + 11):
+        with pytest.raises(SystemExit):
+            cli.encode_file(str(tmp_path / "data.bin"), "dark", bs)
+        assert open(out, "rb").read() == before
+        assert sorted(os.listdir(".")) == ["data.bin", "data.dark", "data.txt"], os.listdir(".")  # no temporary or partial file
+    assert open(cli.decode_file(out, "dark"), "rb").read() == good
+
+
+def test_batch_error_path_is_safe(orc):
+    """a push that fails (here: a block larger than the context) must not leave coding threads running over buffers that are
+    about to be freed: the batch is finished before the error is raised, the context stays usable, and a batch left open is finished by
+    Context.close() / dk_ctx_destroy."""
+    torch = pytest.importorskip("torch")
+    blocks = [np.ascontiguousarray(text_like(np.random.default_rng(5 + i), 150_000)) for i in range(3)]
+    big = np.zeros(400_001, np.uint8)
+    with dark_amd.Context(400_000) as c:
+        b = c.batch_begin("dark", 2)
+        for blk in blocks:
+            b.push(torch.from_numpy(blk).cuda(), len(blk))
+        with pytest.raises(dark_amd.DarkError) as e:  # while a batch is open the context serves nothing else
+            c.block_encode("dark", blocks[0])
+        assert e.value.code == dark_amd._lib.DK_E_ARG
+        with pytest.raises(dark_amd.DarkError):
+            b.push(torch.from_numpy(big).cuda(), len(big))
+        with pytest.raises(dark_amd.DarkError):       # the failed push closed the batch
+            b.finish()
+        assert c.block_encode("dark", blocks[1]) == orc.block_dc_encode("dark", blocks[1])
+        with c.batch_begin("dark", 2) as b2:           # context-manager form; results through finish()
+            for blk in blocks:
+                b2.push(torch.from_numpy(blk).cuda(), len(blk))
+            streams = b2.finish()
+        assert [s.tobytes() for s in streams] == [orc.block_dc_encode("dark", blk) for blk in blocks]
+        b3 = c.batch_begin("dark", 2)                  # left open on purpose: Context.close() must join its coders
+        b3.push(torch.from_numpy(blocks[2]).cuda(), len(blocks[2]))
+    assert b3._h is None
+
+
 def test_raw_block_codec(ctx, orc, license_bytes):
     # block::raw::{Encoder,Decoder} with the dump model Out (src/block/raw.rs:35-104, src/model/raw.rs:46-76)
     import struct

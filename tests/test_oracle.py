@@ -163,3 +163,50 @@ def test_dc_distances_agree_with_dark_c_analogue(orc):
         # every other entry the oracle holds is the final sweep: one per symbol, at its last position, n - last - rank - 1
         extra = {int(p): int(sparse[p]) for p in np.flatnonzero(sparse != n) if int(p) not in r}
         assert extra == {last[s]: n - last[s] - rank - 1 for rank, s in enumerate(mtf)}
+
+
+def test_fullsize_helpers_on_small_blocks(orc):
+    """tests/oracle_jobs.py (background oracle runs) and the checkers of tests/test_gpu_fullsize.py, exercised on the CPU at toy sizes:
+    a correct suffix array passes, a swapped pair and a duplicated index are caught."""
+    torch = pytest.importorskip("torch")
+    import oracle_jobs
+    import test_gpu_fullsize as fs
+    oracle_jobs.start("small_random")
+    job = oracle_jobs.get("small_text")
+    assert job["stream"] == orc.block_dc_encode("dark", job["block"]) and job["origin"] < len(job["block"])
+    assert oracle_jobs.get("small_random")["stream"] is None
+    for t in (job["block"], np.frombuffer(b"ab" * 9000 + b"a", np.uint8), np.zeros(3000, np.uint8)):
+        n = len(t)
+        sa = orc.sa_sais(t)
+        d_t, d_sa = torch.from_numpy(t.copy()), torch.from_numpy(sa.view(np.int32).copy())
+        fs.assert_permutation(d_sa, n)
+        fs.assert_all_neighbours_in_order(d_t, d_sa, n, t, chunk=4096, max_steps=50)  # few steps: the leftovers go to the host compare
+        bad = d_sa.clone()
+        bad[[n // 2, n // 2 + 1]] = bad[[n // 2 + 1, n // 2]]
+        with pytest.raises(AssertionError):
+            fs.assert_all_neighbours_in_order(d_t, bad, n, t, chunk=4096, max_steps=50)
+        dup = d_sa.clone()
+        dup[5] = dup[6]
+        with pytest.raises(AssertionError):
+            fs.assert_permutation(dup, n)
+
+
+def test_bbb_state_tables_agree(orc):
+    """The bit-history table of the bbb model exists three times: the reference's literal (src/model/bbb.rs:34-99), the oracle's copy
+    (oracle/bbb_state_table.inc, generated from that literal) and the product's (dark_amd/csrc/bbb_states.inc, typed in separately).
+    Oracle and product must not share source, so their agreement is checked here -- against each other always, against the
+    reference's literal wherever the reference tree is present (not on the GPU box)."""
+    import os
+    import re
+    from conftest import ROOT
+    theirs = orc.bbb_state_table()
+    text = open(os.path.join(ROOT, "dark_amd", "csrc", "bbb_states.inc")).read()
+    nums = [int(x) for x in re.findall(r"\d+", re.sub(r"//[^\n]*", "", text))]
+    assert len(nums) == 1024
+    assert np.array_equal(np.array(nums, dtype=np.uint8).reshape(256, 4), theirs)
+    if os.path.exists("/root/reference/src/model/bbb.rs"):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("make_bbb_table", os.path.join(ROOT, "oracle", "make_bbb_table.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        assert np.array_equal(np.array(mod.parse_state_table("/root/reference"), dtype=np.uint8), theirs)
