@@ -37,8 +37,13 @@ def parse():
     ap.add_argument("--n", type=int, default=0, help="override the block size (debug)")
     ap.add_argument("--model", default="dark")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=125_000_000,
-                    help="bytes of the block the CPU oracle is timed on (default: the whole block up to 125 MB, about 10 s of one core)")
+    ap.add_argument("--cpu-sample", type=int, default=32_000_000,
+                    help="bytes of the block (a prefix) the CPU oracle is timed on, --cpu-runs times, median reported (default 32 MB x 3: about 15 s of one core)")
+    ap.add_argument("--cpu-runs", type=int, default=3)
+    ap.add_argument("--corpus", default="",
+                    help="a real file instead of the synthetic stand-in (book1, enwik8, enwik9 ...): rank r codes block r of the file cut into blocks of the "
+                         "workload's size (--n overrides); \"data\": \"real\".  Without it, $DARK_CORPUS_DIR/{book1,enwik8,enwik9} is used when the workload "
+                         "is that corpus's stand-in and the file exists")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--pipeline-blocks", type=int, default=15,
                     help="extra leg: this many blocks in flight on one GPU, device stages pipelined against host coding (0 = skip)")
@@ -82,6 +87,34 @@ def launch_ranks(args):
             if p.poll() is None:
                 p.kill()
     return rc
+
+
+CORPUS_OF = {"book1_like_768771": ("book1", 768771), "enwik8_like_1e8": ("enwik8", 100_000_000), "enwik9_block_125e6": ("enwik9", 125_000_000)}
+BOOK1_DARK_FILE_BYTES = 214445  # README.md:20 of the reference: book1 (768 771 B) -> 214 445 B with the `dark` model (4-byte header included)
+
+
+def find_corpus(args):
+    """-> (path, block size) of the real file to use, or (None, 0): --corpus, else $DARK_CORPUS_DIR/<corpus of this workload>"""
+    if args.corpus:
+        if not os.path.isfile(args.corpus):
+            sys.exit("bench.py: --corpus %s: no such file" % args.corpus)
+        return args.corpus, args.n or CORPUS_OF.get(args.workload, (None, 0))[1] or os.path.getsize(args.corpus)
+    d = os.environ.get("DARK_CORPUS_DIR")
+    if d and args.workload in CORPUS_OF and not args.n:
+        name, size = CORPUS_OF[args.workload]
+        path = os.path.join(d, name)
+        if os.path.isfile(path):
+            return path, size
+    return None, 0
+
+
+def read_corpus_block(path, block_bytes, index):
+    """block `index` (modulo the number of blocks) of the file cut into blocks of block_bytes; a memory-mapped slice, copied once"""
+    size = os.path.getsize(path)
+    block_bytes = min(block_bytes, size)
+    nblocks = max(1, size // block_bytes)  # a short tail is left out: every rank codes a block of the same size
+    off = (index % nblocks) * block_bytes
+    return np.fromfile(path, dtype=np.uint8, count=block_bytes, offset=off)
 
 
 def make_block(workload, seed_offset, n_override):
@@ -135,6 +168,18 @@ def stub_exchange(args, world, rank):
         return (rng.integers(0, 1 << 16, size=m, dtype=np.uint32) >> rng.integers(0, 16, size=m).astype(np.uint32)), rng.integers(0, 256, size=m, dtype=np.uint8)
 
     d, sym = rank_input(rank)
+    # the same planning of the host coding threads as the real run: the smallest number of claimable L3 groups over the ranks decides for all
+    from dark_amd import entropy as dk_entropy
+    groups = [dk_entropy.l3_groups(4), dk_entropy.l3_groups(2)]
+    gt = torch.tensor(groups, dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(gt, op=dist.ReduceOp.MIN)
+    share = max(1, cpu_budget() // max(world, args.node_gpus, 1))
+    if "DK_ENTROPY_THREADS" in os.environ:
+        thread_plan = int(os.environ["DK_ENTROPY_THREADS"])
+    else:
+        thread_plan = dk_entropy.plan_threads(int(gt[0]), int(gt[1]), world, share)
+        dk_entropy.set_threads(thread_plan)
 
     def step():
         s = np.frombuffer(model.encode(args.model, d, sym), dtype=np.uint8).copy()  # product host coder (dk_model_encode), no oracle
@@ -152,6 +197,20 @@ def stub_exchange(args, world, rank):
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    # one pass of the block-level host coder (dk_stream_encode: the entry point whose thread form the plan sets) over this rank's
+    # distances, to see which form it really got; then every rank's report goes to rank 0 like in the real run
+    init = np.full(256, 1 << 20, dtype=np.uint32)
+    init[:16] = np.arange(16)
+    te = time.perf_counter()
+    model.stream_encode(args.model, 1 << 20, init, d, sym & 15, 0)
+    te = 1e3 * (time.perf_counter() - te)
+    threads, group = dk_entropy.last_info()
+    mine = rank_report(rank, args.steps, float(time.perf_counter() - t0), {"ms_entropy": te * args.steps}, [threads], [group], groups, len(d), len(stream))
+    reports = [None] * world
+    if world > 1:
+        dist.all_gather_object(reports, mine)
+    else:
+        reports = [mine]
     if rank == 0:
         ok = len(got) == world
         for r, g in enumerate(got):
@@ -159,10 +218,30 @@ def stub_exchange(args, world, rank):
             ok = ok and bool((model.decode(args.model, g.numpy().tobytes(), sr) == dr).all())
         print(json.dumps({"metric": "stub_exchange", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(1e3 * float(el.item()) / args.steps, 3), "gathered_streams_decode": bool(ok),
-                          "stream_bytes": [int(len(g)) for g in got], "backend": "gloo", "data": "synthetic"}))
+                          "stream_bytes": [int(len(g)) for g in got], "backend": "gloo", "data": "synthetic",
+                          "host_cpu_share_per_rank": share, **thread_summary(reports, thread_plan)}))
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def rank_report(rank, steps, elapsed, stage_acc, threads_seen, groups_seen, groups_visible, n, stream_bytes):
+    """what one rank knows about its own timed steps (gathered on rank 0 and printed under "ranks")"""
+    return {"rank": rank, "block_bytes": int(n), "stream_bytes": int(stream_bytes), "ms_per_step": round(1e3 * elapsed / steps, 3),
+            "ms_entropy": round(stage_acc.get("ms_entropy", 0.0) / steps, 3),
+            "ms_device": round((stage_acc.get("ms_sa", 0.0) + stage_acc.get("ms_bwt", 0.0) + stage_acc.get("ms_dc", 0.0) + stage_acc.get("ms_d2h", 0.0)) / steps, 3),
+            "host_entropy_threads": min(threads_seen) if threads_seen else None,
+            "host_entropy_threads_max": max(threads_seen) if threads_seen else None,
+            "l3_group": groups_seen[-1] if groups_seen else None,
+            "l3_groups_with_4_cores": int(groups_visible[0]), "l3_groups_with_2_cores": int(groups_visible[1])}
+
+
+def thread_summary(reports, plan):
+    """-> keys for the JSON line: the plan, every rank's report, and which ranks coded on fewer threads than planned"""
+    want = plan if plan in (1, 2, 4) else None
+    short = [r["rank"] for r in reports if want and r["host_entropy_threads"] is not None and r["host_entropy_threads"] < want]
+    return {"entropy_thread_plan": plan, "ranks": reports, "entropy_fallback_ranks": short,
+            "entropy_fallback": ("ranks %s coded on fewer host threads than planned (%d): max-over-ranks is theirs" % (short, want)) if short else None}
 
 
 def cpu_budget():
@@ -192,11 +271,9 @@ def main():
     import torch  # device_count() does not initialise the GPU on this image
     # Host threads: the ranks of one node share the container's CPU quota.  Every rank gets quota / (GPUs of the node), at every N, so
     # that an N=1 run uses exactly the per-rank resources of an N=8 run on the same node.  The single-block encoder busy-waits on up
-    # to four cores per rank; tell the library to stay within the share (it reads DK_ENTROPY_THREADS once, when it is loaded).
+    # to four cores per rank: the thread form is planned below from this share and from the L3 groups every rank can claim.
     node_gpus = max(args.node_gpus or torch.cuda.device_count(), world, 1)
     share = max(1, cpu_budget() // node_gpus)
-    if "DK_ENTROPY_THREADS" not in os.environ and share < 4:
-        os.environ["DK_ENTROPY_THREADS"] = "2" if share >= 2 else "1"
     args.pipeline_threads = max(1, min(args.pipeline_threads, share - 1))
     import torch.distributed as dist
     import dark_amd
@@ -212,8 +289,30 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
+    # One coding pipeline per rank needs one last-level-cache group per rank.  Every rank reports how many groups it could claim; the
+    # smallest answer decides the thread form of ALL ranks, so that max-over-ranks is not decided by who loses the race for a group.
+    from dark_amd import entropy as dk_entropy
+    groups = [dk_entropy.l3_groups(4), dk_entropy.l3_groups(2)]
+    if world > 1:
+        gt = torch.tensor(groups, dtype=torch.int64)
+        dist.all_reduce(gt, op=dist.ReduceOp.MIN, group=host_group)
+        groups_min = [int(x) for x in gt]
+    else:
+        groups_min = groups
+    if "DK_ENTROPY_THREADS" in os.environ:
+        thread_plan = int(os.environ["DK_ENTROPY_THREADS"])
+    else:
+        thread_plan = dk_entropy.plan_threads(groups_min[0], groups_min[1], world, share)
+        dk_entropy.set_threads(thread_plan)
+
     t_gen = time.time()
-    block = make_block(args.workload, rank, args.n)
+    corpus_path, corpus_block = find_corpus(args)
+    if corpus_path:
+        block = read_corpus_block(corpus_path, corpus_block, rank)
+        workload_name = os.path.basename(corpus_path) if len(block) == os.path.getsize(corpus_path) else "%s_block_%d" % (os.path.basename(corpus_path), len(block))
+    else:
+        block = make_block(args.workload, rank, args.n)
+        workload_name = args.workload if not args.n else "wiki_like_%d" % len(block)
     n = len(block)
     t_gen = time.time() - t_gen
     d_in = torch.from_numpy(block).to(dev)
@@ -242,6 +341,7 @@ def main():
     ctx.stats_reset()
     ctx.set_profiling(True)
     stage_acc = {}
+    threads_seen, groups_seen = [], []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -249,6 +349,8 @@ def main():
         st = ctx.stats()
         for k in ("ms_sa", "ms_bwt", "ms_dc", "ms_d2h", "ms_entropy", "ms_total"):
             stage_acc[k] = stage_acc.get(k, 0.0) + st[k]
+        threads_seen.append(int(st["entropy_threads"]))
+        groups_seen.append(int(st["entropy_l3_group"]))
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.set_profiling(False)
@@ -269,6 +371,13 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed_max = float(tmax.item())
+    # every rank's view of its own timed steps, for rank 0's line: a rank that fell back to fewer coding threads shows here
+    mine = rank_report(rank, args.steps, elapsed, stage_acc, threads_seen, groups_seen, groups, n, len(stream))
+    if world > 1:
+        reports = [None] * world
+        dist.all_gather_object(reports, mine, group=host_group)
+    else:
+        reports = [mine]
 
     # decode leg (same protocol, reported beside the headline)
     decode_mbps = None
@@ -411,7 +520,7 @@ def main():
                     cand = json.load(f)
             except (OSError, ValueError):
                 continue
-            if cand.get("workload") == args.workload and (pmc is None or cand.get("round", 0) >= pmc.get("round", 0)):
+            if not corpus_path and cand.get("workload") == args.workload and (pmc is None or cand.get("round", 0) >= pmc.get("round", 0)):
                 pmc, pmc_path = cand, os.path.relpath(path, ROOT)
         if dom_name:
             dk_ = kern[dom_name]
@@ -452,8 +561,8 @@ def main():
         result = {
             "metric": "bwt_encode_MBps", "value": round(world * n * k / elapsed_max / 1e6, 3), "unit": "MB/s",
             "n_gpus": world, "steps": k, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed_max / k, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64 integer", "data": "synthetic",
-            "config": {"workload": args.workload if not args.n else "wiki_like_%d" % n, "block_bytes": n, "model": args.model,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64 integer", "data": "real" if corpus_path else "synthetic",
+            "config": {"workload": workload_name, "block_bytes": n, "model": args.model,
                        "blocks_per_gpu": 1, "parallelism": "block-per-gpu x%d" % world, "host_cpus_per_rank": share, "node_gpus": node_gpus,
                        "gather": args.gather if world > 1 else "none"},
             "bwt_forward_MBps_per_gpu": round(n / (fwd_ms * 1e-3) / 1e6, 1),
@@ -465,6 +574,7 @@ def main():
             "stage_ms_unprofiled": {kk: round(v, 3) for kk, v in clean_acc.items()},
             "sa_rounds": stats["rounds"], "sort_passes": stats["sort_passes"], "dc_runs": stats["dc_runs"],
             "host_entropy_threads": stats["entropy_threads"], "host_cpu_share_per_rank": share,
+            **thread_summary(reports, thread_plan),
             "kernel_ms_per_step": {kk: round(v["ms"] / k, 3) for kk, v in sorted(kern.items(), key=lambda x: -x[1]["ms"])},
             "roofline": roofline,
             "bwt_forward_roofline": fwd_roofline,
@@ -472,6 +582,12 @@ def main():
             "gather_ms": gather_ms,
             "datagen_s": round(t_gen, 2),
         }
+        if corpus_path:
+            result["corpus"] = {"path": corpus_path, "file_bytes": os.path.getsize(corpus_path), "block_bytes": n}
+            if os.path.basename(corpus_path) == "book1" and n == 768771 and args.model == "dark":
+                # the one number the reference publishes for this path (README.md:20): the .dark file = 4-byte header + stream
+                result["corpus"].update({"dark_file_bytes": int(len(stream)) + 4, "reference_dark_file_bytes": BOOK1_DARK_FILE_BYTES,
+                                         "matches_reference_size": bool(len(stream) + 4 == BOOK1_DARK_FILE_BYTES)})
         if dstats:
             result["decode_stage_ms"] = {kk: round(dstats[kk], 3) for kk in ("ms_entropy", "ms_h2d", "ms_ibwt", "ms_total")}  # last step
             # where the host half of the decode goes, nanoseconds per distance, each part timed alone on this block (rank 0): the range
@@ -504,15 +620,20 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle import orc  # the checker, timed as the CPU baseline (never the thing measured above)
             sample = block[:min(n, args.cpu_sample)]
-            tc = time.perf_counter()
-            ref_stream = orc.block_dc_encode(args.model, sample)
-            tc = time.perf_counter() - tc
-            stages = orc.last_stage_seconds()
+            runs, ref_stream, stages = [], None, None
+            for _ in range(max(1, args.cpu_runs)):
+                tc = time.perf_counter()
+                ref_stream = orc.block_dc_encode(args.model, sample)
+                runs.append(time.perf_counter() - tc)
+                if runs[-1] == sorted(runs)[len(runs) // 2]:
+                    stages = orc.last_stage_seconds()
+            tc = sorted(runs)[len(runs) // 2]
             result["cpu_baseline"] = {"value": round(len(sample) / tc / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
-                                      "sample": "%s of the same block (%d bytes), one block, C restatement of the reference CPU path "
-                                                "(SA-IS + BWT + DC + dark model/range coder)"
-                                                % ("the whole" if len(sample) == n else "a prefix", len(sample)),
-                                      "seconds": round(tc, 2), "stage_s": {kk: round(v, 3) for kk, v in stages.items()}}
+                                      "sample": "%s of the same block (%d bytes) as one block, median of %d runs; C restatement of the reference CPU "
+                                                "path (SA-IS + BWT + DC + dark model/range coder)"
+                                                % ("the whole" if len(sample) == n else "a prefix", len(sample), len(runs)),
+                                      "seconds": round(tc, 2), "seconds_all": [round(x, 2) for x in runs],
+                                      "stage_s": {kk: round(v, 3) for kk, v in (stages or {}).items()}}
             # parity at sample scale: the same prefix through the GPU path must give the identical coded stream
             gpu_sample = stream.tobytes() if len(sample) == n else ctx.dev_block_encode(args.model, d_in[:len(sample)], len(sample)).tobytes()
             result["cpu_baseline"]["gpu_stream_identical_on_sample"] = bool(gpu_sample == ref_stream)

@@ -19,7 +19,7 @@ class Stats(C.Structure):
     _fields_ = [("ms_h2d", C.c_double), ("ms_sa", C.c_double), ("ms_bwt", C.c_double), ("ms_dc", C.c_double),
                 ("ms_d2h", C.c_double), ("ms_entropy", C.c_double), ("ms_ibwt", C.c_double), ("ms_total", C.c_double),
                 ("rounds", C.c_uint32), ("sort_passes", C.c_uint32), ("sorted_elements", C.c_uint64),
-                ("dc_runs", C.c_uint64), ("entropy_threads", C.c_uint32), ("reserved0", C.c_uint32),
+                ("dc_runs", C.c_uint64), ("entropy_threads", C.c_uint32), ("entropy_l3_group", C.c_int32),
                 ("kernel_launches", C.c_uint32 * NUM_KERNEL_SLOTS), ("kernel_ms", C.c_double * NUM_KERNEL_SLOTS),
                 ("kernel_bytes", C.c_double * NUM_KERNEL_SLOTS)]
 
@@ -68,6 +68,9 @@ SIGNATURES = {
     "dk_stats_reset": (_i, [_vp]),
     "dk_get_stats": (_i, [_vp, C.POINTER(Stats)]),
     "dk_kernel_name": (C.c_char_p, [_i]),
+    "dk_set_entropy_threads": (_i, [_i]),
+    "dk_host_l3_groups": (_i, [_i]),
+    "dk_last_entropy_info": (None, [C.POINTER(_i), C.POINTER(_i)]),
     "dk_dbg_sort_pairs": (_i, [_vp, _vp, _vp, _sz, _i, _i]),
 }
 

@@ -136,6 +136,7 @@ int block_encode_common(dk_ctx *ctx, int model_id, const uint8_t *d_text, size_t
     int rc = encode_block_stream(model_id, s, out, out_cap, out_len);
     ctx->stats.ms_entropy = t.ms();
     ctx->stats.entropy_threads = static_cast<uint32_t>(dk::last_entropy_threads());
+    ctx->stats.entropy_l3_group = dk::last_entropy_group();
     if (rc == DK_E_CAPACITY) return ctx->fail(rc, "output buffer of %zu bytes is too small", out_cap);
     if (rc) return ctx->fail(rc, "entropy stage failed (%d)", rc);
     return DK_OK;
@@ -863,6 +864,14 @@ int dk_get_stats(const dk_ctx *ctx, dk_stats *out) {
     return DK_OK;
 }
 const char *dk_kernel_name(int slot) { return kernel_slot_name(slot); }
+
+// ---- host coding threads ------------------------------------------------------------------------------------------------------
+int dk_set_entropy_threads(int mode) { return set_entropy_thread_mode(mode); }
+int dk_host_l3_groups(int min_cores) { return host_l3_groups(min_cores); }
+void dk_last_entropy_info(int *threads, int *l3_group) {
+    if (threads) *threads = last_entropy_threads();
+    if (l3_group) *l3_group = last_entropy_group();
+}
 
 // ---- debug ------------------------------------------------------------------------------------------------------------------
 int dk_dbg_sort_pairs(dk_ctx *ctx, uint64_t *keys, uint32_t *vals, size_t count, int begin_bit, int end_bit) {

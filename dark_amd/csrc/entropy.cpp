@@ -782,6 +782,7 @@ int open_group_lock(int group_id) {
 }
 #endif
 
+void note_group(int id);  // remembers the L3 group the calling thread's coding pass claimed (dk_last_entropy_info)
 struct ThreadPair {
     int me = -1;
 #if defined(__linux__)
@@ -820,6 +821,7 @@ struct ThreadPair {
             group = usable;
             lock_fd = fd;
             me = g.id;
+            note_group(me);
             return true;
         }
         return false;
@@ -1245,16 +1247,47 @@ int cgroup_cpu_budget() {
     return budget;
 }
 
-// 0 = automatic, 1 = one thread, 2 = models | coder, 4 = the four-stage pipeline (dark model), each whenever the cores exist
-int entropy_thread_mode() {
-    static const int mode = [] { const char *e = getenv("DK_ENTROPY_THREADS"); return e ? atoi(e) : 0; }();
-    return mode;
-}
+// 0 = automatic, 1 = one thread, 2 = models | coder, 4 = the four-stage pipeline (dark model), each whenever the cores exist.
+// Process-wide: DK_ENTROPY_THREADS at load time, dk_set_entropy_threads() afterwards (a launcher that has compared what every rank of a
+// node can claim sets the same form on all of them, so that the slowest rank is not decided by who wins the race for an L3 group).
+std::atomic<int> g_thread_mode{[] { const char *e = getenv("DK_ENTROPY_THREADS"); return e ? atoi(e) : 0; }()};
+int entropy_thread_mode() { return g_thread_mode.load(std::memory_order_relaxed); }
 
 }  // namespace
 
 static thread_local int t_last_threads = 1;
+static thread_local int t_last_group = -1;
 int last_entropy_threads() { return t_last_threads; }
+namespace { void note_group(int id) { t_last_group = id; } }
+int last_entropy_group() { return t_last_threads > 1 ? t_last_group : -1; }
+int set_entropy_thread_mode(int mode) {
+    if (mode != 0 && mode != 1 && mode != 2 && mode != 4) return DK_E_ARG;
+    g_thread_mode.store(mode, std::memory_order_relaxed);
+    return DK_OK;
+}
+// last-level-cache groups in which the calling thread's affinity mask leaves at least min_cores cores (what ThreadPair::acquire looks for)
+int host_l3_groups(int min_cores) {
+#if defined(__linux__)
+    cpu_set_t mask;
+    if (min_cores < 1 || pthread_getaffinity_np(pthread_self(), sizeof(mask), &mask) != 0) return 0;
+    const Topology &topo = topology();
+    int count = 0;
+    for (const L3Group &g : topo.groups) {
+        cpu_set_t usable;
+        CPU_AND(&usable, &g.primary, &mask);
+        size_t cores = static_cast<size_t>(CPU_COUNT(&usable));
+        if (cores < static_cast<size_t>(min_cores)) {
+            CPU_AND(&usable, &g.cpus, &mask);
+            cores = (static_cast<size_t>(CPU_COUNT(&usable)) + topo.threads_per_core - 1) / topo.threads_per_core;
+        }
+        count += cores >= static_cast<size_t>(min_cores) ? 1 : 0;
+    }
+    return count;
+#else
+    (void)min_cores;
+    return 0;
+#endif
+}
 
 int encode_block_stream(int model_id, const DcStream &s, uint8_t *out, size_t cap, size_t *out_len, int host_threads) {
     if (!s.init || (!s.dist && s.m) || (!s.sym && s.m) || !out || !out_len) return DK_E_ARG;
@@ -1264,6 +1297,7 @@ int encode_block_stream(int model_id, const DcStream &s, uint8_t *out, size_t ca
         model.reset();  // Encoder::new resets the model (src/block/dc.rs:31)
         const int mode = host_threads ? host_threads : entropy_thread_mode();
         t_last_threads = 1;
+        t_last_group = -1;
         const bool large = s.m >= (1u << 21);
         const int budget = cgroup_cpu_budget();
         if (mode == 4 || (mode == 0 && large && budget >= 4)) {

@@ -480,6 +480,9 @@ struct DcStream {          // what the GPU DC stage hands to the entropy stage
 // host_threads: 0 = automatic (two threads for large blocks when a partner core sharing the L3 can be pinned), 1 = one thread
 int encode_block_stream(int model_id, const DcStream &s, uint8_t *out, size_t cap, size_t *out_len, int host_threads = 0);
 int last_entropy_threads();  // threads the calling thread's last encode_block_stream used
+int last_entropy_group();    // and the last-level-cache group (lowest cpu number in it) that pass claimed; -1: none (one thread)
+int set_entropy_thread_mode(int mode);  // 0 automatic | 1 | 2 | 4, process-wide (overrides DK_ENTROPY_THREADS)
+int host_l3_groups(int min_cores);      // L3 groups with at least min_cores cores usable by the calling thread
 // src/block/dc.rs:121-151: header, dc::decode pulling model.decode, origin.  *single = 1 when the block has a
 // one-symbol alphabet (the reference then mis-reads origin; see DESIGN.md "Reference quirks").
 int decode_block_stream(int model_id, const uint8_t *in, size_t in_len, size_t n, uint8_t *bwt_out,

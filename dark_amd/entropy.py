@@ -29,3 +29,33 @@ def decode_bits(stream, flat):
     if rc:
         raise DarkError(rc)
     return bits
+
+
+# ---- host coding threads (include/dark_amd.h "host coding threads") ----------------------------------------------------------------
+def set_threads(mode):
+    """thread form of the host coding pass, process-wide: 0 automatic | 1 | 2 | 4"""
+    rc = _lib.load().dk_set_entropy_threads(int(mode))
+    if rc:
+        raise DarkError(rc, "dk_set_entropy_threads(%r)" % (mode,))
+
+
+def l3_groups(min_cores):
+    """last-level-cache groups in which the calling thread may use at least min_cores cores"""
+    return int(_lib.load().dk_host_l3_groups(int(min_cores)))
+
+
+def last_info():
+    """(threads, l3_group) of the calling thread's last host coding pass; l3_group -1 = none claimed"""
+    t, g = C.c_int(0), C.c_int(0)
+    _lib.load().dk_last_entropy_info(C.byref(t), C.byref(g))
+    return int(t.value), int(g.value)
+
+
+def plan_threads(groups4, groups2, ranks, share):
+    """The thread form every rank of a node should use so that none of them loses the race for an L3 group: groups4 / groups2 = the
+    SMALLEST number of groups with >= 4 / >= 2 usable cores any rank sees, ranks = ranks on the node, share = host CPUs per rank."""
+    if share >= 4 and groups4 >= ranks:
+        return 4
+    if share >= 2 and groups2 >= ranks:
+        return 2
+    return 1

@@ -187,7 +187,7 @@ typedef struct dk_stats {
     uint64_t sorted_elements; /* sum over passes of elements moved */
     uint64_t dc_runs;         /* m of the last dc encode */
     uint32_t entropy_threads; /* host threads the last range-coder pass used: 1, 2 (models | coder) or 4 (two model halves, merger, coder) */
-    uint32_t reserved0;
+    int32_t entropy_l3_group; /* the last-level-cache group that pass claimed for its threads (lowest cpu number in it); -1: none */
     /* per-kernel HIP-event timings accumulated since dk_stats_reset (only while profiling is enabled) */
     uint32_t kernel_launches[DK_NUM_KERNEL_SLOTS];
     double kernel_ms[DK_NUM_KERNEL_SLOTS];
@@ -199,6 +199,17 @@ int dk_stats_reset(dk_ctx *ctx);
 int dk_get_stats(const dk_ctx *ctx, dk_stats *out);
 /* name of kernel slot i (NULL past the end) */
 const char *dk_kernel_name(int slot);
+
+/* ---- host coding threads (operations; nothing in the reference corresponds: its coder is one thread) ------------------------------------
+ * A large single block is coded by a pipeline of 2 or 4 host threads confined to one last-level-cache group; groups are
+ * claimed per process, and a process that finds none free codes on one thread.  A launcher of several ranks per node can make that
+ * deterministic: ask every rank how many groups it could claim, and set the same form everywhere. */
+/* thread form of the host coding pass, process-wide: 0 automatic (default; or DK_ENTROPY_THREADS at load time) | 1 | 2 | 4 */
+int dk_set_entropy_threads(int mode);
+/* number of last-level-cache groups in which the calling thread may use at least min_cores cores */
+int dk_host_l3_groups(int min_cores);
+/* the calling thread's last host coding pass: threads used (1 / 2 / 4) and the L3 group claimed (-1: none).  Either may be NULL. */
+void dk_last_entropy_info(int *threads, int *l3_group);
 
 /* ---- stage-level debug entry points used by the parity tests ------------------------------------------------ */
 /* stable LSD radix sort of (u64 key, u32 value) pairs on bits [begin_bit, end_bit) -- the workhorse of the suffix sort */

@@ -94,6 +94,37 @@ def test_bench_launcher_starts_n_ranks():
     the exchange: same launcher, same exchange_streams() code path, backend gloo, streams from the product's host coder."""
     res = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--stub-exchange"])
     assert res["n_gpus"] == 2 and res["gathered_streams_decode"] is True and len(res["stream_bytes"]) == 2
+    _check_rank_reports(res, 2)
+
+
+def _check_rank_reports(res, world):
+    """the line carries EVERY rank's host coding form (threads, claimed L3 group, ms_entropy), the form planned for
+    all ranks together, and says so when a rank coded on fewer threads than planned."""
+    from dark_amd import entropy
+    plan = res["entropy_thread_plan"]
+    assert plan in (1, 2, 4) and [r["rank"] for r in res["ranks"]] == list(range(world))
+    g4 = min(r["l3_groups_with_4_cores"] for r in res["ranks"])
+    g2 = min(r["l3_groups_with_2_cores"] for r in res["ranks"])
+    # deterministic: when there are fewer claimable L3 groups than ranks, ALL ranks drop to the narrower form together
+    assert plan == entropy.plan_threads(g4, g2, world, res["host_cpu_share_per_rank"])
+    for r in res["ranks"]:
+        assert {"ms_entropy", "ms_per_step", "host_entropy_threads", "l3_group", "stream_bytes"} <= set(r)
+        assert 1 <= r["host_entropy_threads"] <= plan
+        assert (r["l3_group"] >= 0) == (r["host_entropy_threads"] > 1)
+    short = [r["rank"] for r in res["ranks"] if r["host_entropy_threads"] < plan]
+    assert res["entropy_fallback_ranks"] == short and (res["entropy_fallback"] is None) == (not short)
+
+
+def test_thread_plan_is_deterministic():
+    from dark_amd import entropy
+    assert entropy.plan_threads(16, 16, 8, 8) == 4      # a group of four cores for every rank
+    assert entropy.plan_threads(7, 16, 8, 8) == 2       # one rank would lose the race for a 4-core group: everybody takes two threads
+    assert entropy.plan_threads(7, 7, 8, 8) == 1
+    assert entropy.plan_threads(16, 16, 8, 3) == 2 and entropy.plan_threads(16, 16, 8, 1) == 1  # the CPU share caps the form
+    assert entropy.l3_groups(1) >= entropy.l3_groups(2) >= entropy.l3_groups(4) >= 0
+    with pytest.raises(Exception):
+        entropy.set_threads(3)
+    entropy.set_threads(0)
 
 
 @pytest.mark.timeout(300)
@@ -102,6 +133,7 @@ def test_bench_under_torchrun():
     res = _run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                       "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--stub-exchange"])
     assert res["n_gpus"] == 2 and res["gathered_streams_decode"] is True
+    _check_rank_reports(res, 2)
 
 
 def test_bench_rejects_mismatched_world():
