@@ -1,5 +1,6 @@
 #include "context.hpp"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace dk {
@@ -8,13 +9,20 @@ const char *kernel_slot_name(int slot) {
     // a slot is named after the kernel it brackets, exactly as rocprofv3 prints it; a slot that brackets several kernels launched
     // back to back carries their common prefix (k_radix_scan = k_radix_scan_a + _b + _c, see the enum)
     static const char *names[K_SLOT_COUNT] = {
-        "k_sym_hist",     "k_pack_keys",    "k_radix_hist",  "k_radix_scan",    "k_radix_scatter", "k_rerank_reduce", "k_rerank_scan",
+        "k_sym_hist",     "k_radix_hist",  "k_radix_scan",    "k_radix_scatter", "k_rerank_reduce", "k_rerank_scan",
         "k_rerank_apply", "k_round_local",  "k_bwt_gather",  "k_dc_summary",    "k_dc_carry",      "k_dc_main",       "k_dc_sweep",
         "k_ibwt_hist",    "k_ibwt_lf",      "k_ibwt_walk",   "k_ibwt_jump",     "k_ibwt_emit",     "k_bucket_store",  "k_big_classify",
         "k_big_back",     "k_prefix_probe", "k_place_active", "k_plateau_sort", "k_plateau_ranks",
-        "k_radix_sort_small", "k_radix_hist_text", "k_radix_scatter_text"};
+        "k_radix_sort_small", "k_radix_hist_text", "k_radix_scatter_text", "k_isa_partition", "k_isa_assemble"};
     return (slot >= 0 && slot < K_SLOT_COUNT) ? names[slot] : nullptr;
 }
+
+#ifdef DK_TUNING
+int tuning_knob(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e && e[0] ? atoi(e) : dflt;
+}
+#endif
 
 }  // namespace dk
 

@@ -18,7 +18,6 @@ namespace dk {
 // kernel slots for dk_stats (index into kernel_ms / kernel_bytes / kernel_launches)
 enum KernelSlot : int {
     K_SYM_HIST = 0,
-    K_PACK_KEYS,
     K_RADIX_HIST,
     K_RADIX_SCAN,      // k_radix_scan_a + _b + _c (one bracket)
     K_RADIX_SCATTER,
@@ -46,6 +45,8 @@ enum KernelSlot : int {
     K_RADIX_SORT_SMALL,
     K_RADIX_HIST_TEXT,     // k_radix_hist<false, true>: first pass, digits straight from the text (1 B per key)
     K_RADIX_SCATTER_TEXT,  // k_radix_scatter<false, true>: first pass, keys built from the text (13 B per pair)
+    K_ISA_PARTITION,       // k_isa_count + k_isa_offsets, k_isa_scatter (inverse permutation through LDS windows)
+    K_ISA_ASSEMBLE,        // k_isa_assemble
     K_SLOT_COUNT
 };
 static_assert(K_SLOT_COUNT <= DK_NUM_KERNEL_SLOTS, "grow DK_NUM_KERNEL_SLOTS");
@@ -127,6 +128,16 @@ struct LaunchScope {
     ~LaunchScope() { if (c->profiling) c->prof_end(); }
 };
 
+// A/B switches of the kernels' variants (DK_XCD, DK_PREFIX, DK_RADIX_WIDE ...): read from the environment only in the TUNING build
+// (-DDK_TUNING: dark_amd/libdark_amd_tuning.so, what tests/test_env_variants.py and tools/stage_time.py load); the product library has
+// every switch compiled in as its default and never looks at the environment for them.
+#ifdef DK_TUNING
+int tuning_knob(const char *name, int dflt);
+#define DK_KNOB(name, dflt) ([] { static const int v_ = dk::tuning_knob(name, dflt); return v_; }())
+#else
+#define DK_KNOB(name, dflt) (dflt)
+#endif
+
 inline size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
 inline unsigned ceil_log2_u64(uint64_t v) {  // smallest b with (1 << b) >= v
     unsigned b = 0;
@@ -138,8 +149,14 @@ inline unsigned ceil_log2_u64(uint64_t v) {  // smallest b with (1 << b) >= v
 // radix_sort.hip
 // first pass of the suffix sort's initial sort straight from the text: key(i) = packed codes of T[i .. i+spk) (<< 8 | code of T[i-1])
 struct TextKeys { const uint8_t *t = nullptr; size_t n = 0; const uint8_t *code = nullptr; int bits = 0, spk = 0, with_prev = 0; };
+// What the LAST pass of a sort writes beside the sorted keys (the suffix sort's initial sort): the values go to `vals` (the suffix array:
+// every suffix at its slot) instead of the ping-pong buffer, and -- when bwt is given -- L[slot] = inv_code[low byte of the key] (the
+// symbol in front of the suffix rides in the key's low byte) and *origin = the slot of value 0.  A later stage overwrites the entries of
+// suffixes that are not final yet.
+struct SortFinalOut { uint32_t *vals = nullptr; uint8_t *bwt = nullptr; const uint8_t *inv_code = nullptr; uint32_t *origin = nullptr; };
+// final_out (may be null; only with the sort of more than 8192 pairs): see SortFinalOut; then `vals` / `vals_alt` are both free on return
 int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
-               int begin_bit, int end_bit, const TextKeys *text = nullptr);
+               int begin_bit, int end_bit, const TextKeys *text = nullptr, const SortFinalOut *final_out = nullptr);
 int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, size_t count, size_t limit, uint64_t *scratch,
                          uint32_t *dst);
 // suffix_array.hip: d_sa_out may alias nothing in the workspace; d_text is caller or ctx owned

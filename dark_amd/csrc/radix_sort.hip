@@ -15,6 +15,7 @@
 // histograms accumulated while scattering -- were built and measured in round 1: 2.2 TB/s and 1.04 ms per pass of 1e8 pairs against
 // 0.81 ms for these three phases.  They lost and were removed; DESIGN.md section 4.1 keeps the numbers.)
 #include "context.hpp"
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))
                                                              const uint32_t *__restrict__ pair_lo,
                                                              uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n,
                                                              int shift, const uint32_t *__restrict__ tile_offs, uint32_t xcd_tiles,
-                                                             TextKeys tk, uint8_t *__restrict__ next_digit) {
+                                                             TextKeys tk, uint8_t *__restrict__ next_digit, SortFinalOut fin) {
     __shared__ uint64_t s_keys[RS_TILE];          // tile of keys in digit order; reused for the values
     // per-wave digit counters (then exclusive over waves) | tile-local start of each digit | global offset of the digit minus its
     // tile-local start.  TEXT: the same 6 KiB first hold the staged codes of the tile (the counters are cleared afterwards).
@@ -383,6 +384,7 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))
         if (p < valid) {
             kout[gi[k]] = kk;
             if (next_digit) next_digit[gi[k]] = static_cast<uint8_t>(digit_of(kk, shift + 8));  // what the next pass's histogram reads
+            if (fin.bwt) fin.bwt[gi[k]] = fin.inv_code[kk & 0xFFu];  // last pass of the suffix sort's initial sort: L rides in the key's low byte
         }
     }
     if (PAIRS) return;  // keys only
@@ -394,7 +396,11 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))
 #pragma unroll
     for (int k = 0; k < RS_KPT; ++k) {
         const uint32_t p = k * RS_BLOCK + tid;
-        if (p < valid) vout[gi[k]] = s_vals[p];
+        if (p < valid) {
+            const uint32_t v = s_vals[p];
+            vout[gi[k]] = v;
+            if (fin.origin && v == 0) *fin.origin = gi[k];  // suffix 0 (if it is not final yet, the stage that makes it final writes again)
+        }
     }
 }
 
@@ -484,8 +490,12 @@ __global__ __launch_bounds__(SS_BLOCK) void k_radix_sort_small(uint64_t *__restr
 
 // Sorts `count` pairs on key bits [begin_bit, end_bit).  keys/vals are the input buffers, *_alt equally sized scratch;
 // on return `keys` and `vals` refer to whichever buffer holds the sorted data (the references are swapped per pass).
+// Wider digits were built and measured in round 3 (passes of 10 / 9 bits over super-tiles of 16384 pairs with 16-bit LDS counters:
+// 56 bits in six passes, 40 bits in four): every pass got 1.6 x slower -- 1024 digits cut a tile's output into runs of four pairs
+// (32 bytes of keys, 16 of values), more partial lines than the L2 merges -- 2^28 ACGT 17.5 against 13.4 ms, 1e8 text 15.2 against
+// 14.0 ms (profiles/r03_wide_digit_experiment.log).  Removed; eight bits per pass stay.
 static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
-                              int begin_bit, int end_bit, const TextKeys *text) {
+                              int begin_bit, int end_bit, const TextKeys *text, const SortFinalOut *final_out) {
     const size_t ntiles = div_up(count, RS_TILE);
     const size_t tiles_per_chunk = div_up(ntiles, RS_MAX_CHUNKS);
     const size_t nchunks = div_up(ntiles, tiles_per_chunk);
@@ -495,8 +505,7 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
     // digit plane: every scatter but the last leaves the next pass's digits behind, one byte per pair.  The histograms get 2x faster,
     // the scatters 15 % slower (the plane's 16-byte runs cost as many L2 write requests as the 64-byte runs of the values).  Measured
     // net gain: 1.4 % at 1e8 pairs (inside the box-to-box variation), 2 % at 2^28, 3.7 % at 2^30: on from 2^28 pairs.
-    // DK_DIGIT_PLANE=1 / 0: always (from 2^20 pairs) / never.
-    static const int plane_mode = [] { const char *e = getenv("DK_DIGIT_PLANE"); return e ? atoi(e) : -1; }();
+    const int plane_mode = DK_KNOB("DK_DIGIT_PLANE", -1);  // tuning build: 1 / 0 = always (from 2^20 pairs) / never
     const size_t plane_from = plane_mode == 1 ? (size_t(1) << 20) : (size_t(1) << 28);
     uint8_t *plane = plane_mode != 0 && end_bit - begin_bit > 8 && count >= plane_from ? ctx->ws_try_alloc<uint8_t>(count) : nullptr;  // optional: the sort runs without it
     if (!tile_hist || !chunk_sum) return DK_E_NOMEM;
@@ -504,10 +513,14 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
     for (int shift = begin_bit; shift < end_bit; shift += 8) {
         const bool have_plane = plane && shift > begin_bit;      // written by the previous pass
         uint8_t *emit = plane && shift + 8 < end_bit ? plane : nullptr;  // read by the next one
+        const TextKeys *tk = text && shift == begin_bit ? text : nullptr;
+        const bool last = shift + 8 >= end_bit;
+        const SortFinalOut fin = last && final_out ? *final_out : SortFinalOut{};
+        uint32_t *vout = fin.vals ? fin.vals : vals_alt;
         {
-            LaunchScope ls(ctx, text && shift == begin_bit ? K_RADIX_HIST_TEXT : K_RADIX_HIST, (text && shift == begin_bit ? 1.0 : have_plane ? 1.0 : 8.0) * count);
-            if (text && shift == begin_bit)
-                k_radix_hist<false, true><<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(nullptr, nullptr, nullptr, count, shift, tile_hist, *text);
+            LaunchScope ls(ctx, tk ? K_RADIX_HIST_TEXT : K_RADIX_HIST, (tk ? 1.0 : have_plane ? 1.0 : 8.0) * count);
+            if (tk)
+                k_radix_hist<false, true><<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(nullptr, nullptr, nullptr, count, shift, tile_hist, *tk);
             else if (have_plane)
                 k_radix_hist_plane<<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(plane, count, tile_hist);
             else
@@ -524,19 +537,19 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
             }
         }
         {
-            LaunchScope ls(ctx, text && shift == begin_bit ? K_RADIX_SCATTER_TEXT : K_RADIX_SCATTER, ((text && shift == begin_bit ? 13.0 : 24.0) + (emit ? 1.0 : 0.0)) * count);
-            static const bool xcd = [] { const char *e = getenv("DK_XCD"); return !(e && e[0] == '0'); }();
+            LaunchScope ls(ctx, tk ? K_RADIX_SCATTER_TEXT : K_RADIX_SCATTER, ((tk ? 13.0 : 24.0) + (emit ? 1.0 : 0.0) + (fin.bwt ? 1.0 : 0.0)) * count);
+            const bool xcd = DK_KNOB("DK_XCD", 1) != 0;
             const size_t grid = xcd ? 8 * div_up(ntiles, 8) : ntiles;
-            if (text && shift == begin_bit)
-                k_radix_scatter<false, true><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(nullptr, nullptr, nullptr, keys_alt, vals_alt, count, shift, tile_hist,
-                                                                                   xcd ? static_cast<uint32_t>(ntiles) : 0u, *text, emit);
+            if (tk)
+                k_radix_scatter<false, true><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(nullptr, nullptr, nullptr, keys_alt, vout, count, shift, tile_hist,
+                                                                                   xcd ? static_cast<uint32_t>(ntiles) : 0u, *tk, emit, fin);
             else
-                k_radix_scatter<false><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(keys, vals, nullptr, keys_alt, vals_alt, count, shift, tile_hist,
-                                                                             xcd ? static_cast<uint32_t>(ntiles) : 0u, TextKeys{}, emit);
+                k_radix_scatter<false><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(keys, vals, nullptr, keys_alt, vout, count, shift, tile_hist,
+                                                                             xcd ? static_cast<uint32_t>(ntiles) : 0u, TextKeys{}, emit, fin);
         }
         DK_HIP(ctx, hipGetLastError());
         std::swap(keys, keys_alt);
-        std::swap(vals, vals_alt);
+        if (!fin.vals) std::swap(vals, vals_alt);  // (the last pass wrote the values to their final home: both ping-pong buffers are free)
         ctx->stats.sort_passes += 1;
         ctx->stats.sorted_elements += count;
     }
@@ -547,7 +560,8 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
 // text != nullptr: the pairs are (key of position i per TextKeys, i) for i < count = text->n; keys / vals need not hold anything on
 // entry (they are scratch), the first pass builds the keys from the text.
 int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
-               int begin_bit, int end_bit, const TextKeys *text) {
+               int begin_bit, int end_bit, const TextKeys *text, const SortFinalOut *final_out) {
+    if (final_out && !text) return ctx->fail(DK_E_INTERNAL, "sort_pairs: a final destination only with the text pass");
     if (count > 0xFFFFFFFEull) return ctx->fail(DK_E_ARG, "sort_pairs: count too large");
     if (text && (count != text->n || end_bit <= begin_bit)) return ctx->fail(DK_E_INTERNAL, "sort_pairs: text pass needs at least one digit");
     if (!text && (count <= 1 || end_bit <= begin_bit)) return DK_OK;
@@ -562,7 +576,7 @@ int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&val
         ctx->stats.sorted_elements += count * static_cast<size_t>(npasses);
         return DK_OK;
     }
-    return sort_pairs_classic(ctx, keys, keys_alt, vals, vals_alt, count, begin_bit, end_bit, text);
+    return sort_pairs_classic(ctx, keys, keys_alt, vals, vals_alt, count, begin_bit, end_bit, text, final_out);
 }
 
 // ---- bucketed scatter: dst[idx[i]] = val[i] for a huge, random idx ---------------------------------------------------
@@ -586,10 +600,136 @@ __global__ __launch_bounds__(RS_BLOCK) void k_bucket_store(const uint64_t *__res
     }
 }
 
+// ---- inverse permutation through LDS windows: rank[sa[p]] = p for a permutation sa of 0..n-1, n <= 2^27 ------------------------------
+// The bucketed store above leans on the L2 to complete the destination lines of a 1.5 MiB window before it writes them back; the
+// counters say it does not (round 2, 1e8: WRITE_SIZE 2.27 GB for 0.40 GB of rank stores).  Here the destination is cut into windows of
+// W = 2^15 words that fit the LDS, and every word leaves for HBM exactly once, in a full coalesced line:
+//   k_isa_count    G workgroups, each over a contiguous stretch of p: how many of its sa[p] fall into each window (LDS histogram)
+//   k_isa_offsets  per window: where each workgroup's pairs start.  sa is a permutation, so window d holds EXACTLY the W suffixes
+//                  [d W, (d+1) W): its pairs occupy [d W, (d+1) W) of the pair array -- no scan over windows is needed
+//   k_isa_scatter  pairs (sa[p], p) to their window's stretch of the pair array; the order inside a window does not matter, so a
+//                  pair's place is one LDS atomic on its window's running counter (no ranking, no reordering)
+//   k_isa_assemble one workgroup per window: pairs -> LDS[suffix - d W] = p -> rank[d W ...] streamed out
+// Algorithmic bytes: 4 n + (4 n + 8 n) + (8 n + 4 n) = 28 n.
+constexpr int ISA_BLOCK = 1024;
+constexpr int ISA_WBITS = 15;                 // window = 32768 words = 128 KiB of LDS
+constexpr int ISA_MAX_WINDOWS = 4096;         // n <= 2^27
+constexpr size_t ISA_MAX_N = size_t(1) << (ISA_WBITS + 12);
+
+__global__ __launch_bounds__(ISA_BLOCK) void k_isa_count(const uint32_t *__restrict__ sa, size_t n, size_t per, int wbits, uint32_t nwin,
+                                                          uint32_t *__restrict__ wg_hist) {
+    __shared__ uint32_t h[ISA_MAX_WINDOWS];
+    for (uint32_t i = threadIdx.x; i < nwin; i += ISA_BLOCK) h[i] = 0;
+    __syncthreads();
+    const size_t p0 = static_cast<size_t>(blockIdx.x) * per;  // per is a multiple of 4: the stretch starts on a 16-byte boundary
+    const size_t p1 = p0 + per < n ? p0 + per : n;
+    const size_t full = p0 + ((p1 - p0) & ~static_cast<size_t>(3));
+    for (size_t p = p0 + 4 * static_cast<size_t>(threadIdx.x); p < full; p += 4 * ISA_BLOCK) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(sa + p);
+        atomicAdd(&h[v.x >> wbits], 1u);
+        atomicAdd(&h[v.y >> wbits], 1u);
+        atomicAdd(&h[v.z >> wbits], 1u);
+        atomicAdd(&h[v.w >> wbits], 1u);
+    }
+    for (size_t p = full + threadIdx.x; p < p1; p += ISA_BLOCK) atomicAdd(&h[sa[p] >> wbits], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nwin; i += ISA_BLOCK) wg_hist[static_cast<size_t>(blockIdx.x) * nwin + i] = h[i];
+}
+// one thread per window: counts -> start of every workgroup's pairs inside the window's stretch (which begins at d << wbits)
+__global__ __launch_bounds__(256) void k_isa_offsets(uint32_t *__restrict__ wg_hist, uint32_t nwg, uint32_t nwin, int wbits) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= nwin) return;
+    uint32_t run = d << wbits;
+#pragma unroll 8
+    for (uint32_t g = 0; g < nwg; ++g) {
+        const uint32_t c = wg_hist[static_cast<size_t>(g) * nwin + d];
+        wg_hist[static_cast<size_t>(g) * nwin + d] = run;
+        run += c;
+    }
+}
+__global__ __launch_bounds__(ISA_BLOCK) void k_isa_scatter(const uint32_t *__restrict__ sa, size_t n, size_t per, int wbits, uint32_t nwin,
+                                                            const uint32_t *__restrict__ wg_hist, uint64_t *__restrict__ pairs) {
+    __shared__ uint32_t next[ISA_MAX_WINDOWS];
+    for (uint32_t i = threadIdx.x; i < nwin; i += ISA_BLOCK) next[i] = wg_hist[static_cast<size_t>(blockIdx.x) * nwin + i];
+    __syncthreads();
+    const size_t p0 = static_cast<size_t>(blockIdx.x) * per;
+    const size_t p1 = p0 + per < n ? p0 + per : n;
+    const size_t full = p0 + ((p1 - p0) & ~static_cast<size_t>(3));
+    for (size_t p = p0 + 4 * static_cast<size_t>(threadIdx.x); p < full; p += 4 * ISA_BLOCK) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(sa + p);
+        const uint32_t s4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t at = atomicAdd(&next[s4[j] >> wbits], 1u);
+            pairs[at] = (static_cast<uint64_t>(s4[j]) << 32) | static_cast<uint32_t>(p + j);
+        }
+    }
+    for (size_t p = full + threadIdx.x; p < p1; p += ISA_BLOCK) {
+        const uint32_t v = sa[p];
+        const uint32_t at = atomicAdd(&next[v >> wbits], 1u);
+        pairs[at] = (static_cast<uint64_t>(v) << 32) | static_cast<uint32_t>(p);
+    }
+}
+__global__ __launch_bounds__(ISA_BLOCK) void k_isa_assemble(const uint64_t *__restrict__ pairs, size_t n, int wbits, uint32_t *__restrict__ rank) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t win[];
+    const size_t base = static_cast<size_t>(blockIdx.x) << wbits;
+    const uint32_t w = 1u << wbits;
+    const uint32_t count = static_cast<uint32_t>(n - base < w ? n - base : w);
+    const uint32_t even = count & ~1u;
+    for (uint32_t i = 2 * threadIdx.x; i < even; i += 2 * ISA_BLOCK) {  // base is a multiple of 1024 pairs: 16-byte aligned loads
+        const uint4 v = *reinterpret_cast<const uint4 *>(pairs + base + i);
+        win[v.y & (w - 1)] = v.x;  // (suffix << 32 | p): y = suffix, x = p
+        win[v.w & (w - 1)] = v.z;
+    }
+    if (threadIdx.x == 0 && even < count) {
+        const uint64_t v = pairs[base + even];
+        win[static_cast<uint32_t>(v >> 32) & (w - 1)] = static_cast<uint32_t>(v);
+    }
+    __syncthreads();
+    const uint32_t quads = count & ~3u;
+    for (uint32_t i = 4 * threadIdx.x; i < quads; i += 4 * ISA_BLOCK)
+        *reinterpret_cast<uint4 *>(rank + base + i) = *reinterpret_cast<const uint4 *>(win + i);
+    if (threadIdx.x < count - quads) rank[base + quads + threadIdx.x] = win[quads + threadIdx.x];
+}
+
+// rank[sa[p]] = p; sa must be a permutation of 0..n-1, n <= ISA_MAX_N; `scratch` holds n u64
+static int inverse_permutation_windows(dk_ctx *ctx, const uint32_t *sa, size_t n, uint64_t *scratch, uint32_t *rank) {
+    const int wbits = n > (size_t(1) << (10 + 12)) ? static_cast<int>(ceil_log2_u64(n)) - 12 : 10;  // at most 4096 windows of at least 1024 words
+    const uint32_t nwin = static_cast<uint32_t>(div_up(n, size_t(1) << wbits));
+    const uint32_t nwg = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(512, div_up(n, 16 * ISA_BLOCK))));
+    const size_t per = (div_up(n, nwg) + 3) & ~static_cast<size_t>(3);
+    const size_t mark = ctx->ws_mark();
+    uint32_t *wg_hist = ctx->ws_alloc<uint32_t>(static_cast<size_t>(nwg) * nwin);
+    if (!wg_hist) return DK_E_NOMEM;
+    hipStream_t st = ctx->stream;
+    {
+        LaunchScope ls(ctx, K_ISA_PARTITION, 4.0 * n);
+        k_isa_count<<<dim3(nwg), dim3(ISA_BLOCK), 0, st>>>(sa, n, per, wbits, nwin, wg_hist);
+        k_isa_offsets<<<dim3(div_up(nwin, 256)), dim3(256), 0, st>>>(wg_hist, nwg, nwin, wbits);
+    }
+    {
+        LaunchScope ls(ctx, K_ISA_PARTITION, 12.0 * n);
+        k_isa_scatter<<<dim3(nwg), dim3(ISA_BLOCK), 0, st>>>(sa, n, per, wbits, nwin, wg_hist, scratch);
+    }
+    {
+        LaunchScope ls(ctx, K_ISA_ASSEMBLE, 12.0 * n);
+        static const bool lds_ok = [] {  // a workgroup may declare more than the default 64 KiB of dynamic LDS only after this
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(k_isa_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, 4 << ISA_WBITS) == hipSuccess;
+        }();
+        if (!lds_ok) return ctx->fail(DK_E_HIP, "k_isa_assemble: cannot reserve %d bytes of LDS", 4 << ISA_WBITS);
+        k_isa_assemble<<<dim3(nwin), dim3(ISA_BLOCK), sizeof(uint32_t) << wbits, st>>>(scratch, n, wbits, rank);
+    }
+    DK_HIP(ctx, hipGetLastError());
+    ctx->ws_release(mark);
+    return DK_OK;
+}
+
 // dst[idx[i]] = val[i] (val == nullptr: = i), i < count; idx values are distinct and < limit.  `scratch` holds count u64.
+// val == nullptr with count == limit is the inverse of a permutation: up to 2^27 entries it goes through LDS windows.
 int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, size_t count, size_t limit, uint64_t *scratch,
                          uint32_t *dst) {
     if (count == 0) return DK_OK;
+    if (!val && count == limit && count <= ISA_MAX_N) return inverse_permutation_windows(ctx, idx, count, scratch, dst);
     const size_t ntiles = div_up(count, RS_TILE);
     const size_t tiles_per_chunk = div_up(ntiles, RS_MAX_CHUNKS);
     const size_t nchunks = div_up(ntiles, tiles_per_chunk);
@@ -614,13 +754,13 @@ int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, 
     {
         LaunchScope ls(ctx, K_RADIX_SCATTER, 16.0 * count);
         k_radix_scatter<true><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(nullptr, idx, val, scratch, nullptr, count, shift, tile_hist,
-                                                                       static_cast<uint32_t>(ntiles), TextKeys{}, nullptr);
+                                                                       static_cast<uint32_t>(ntiles), TextKeys{}, nullptr, SortFinalOut{});
     }
     {
         LaunchScope ls(ctx, K_BUCKET_STORE, 12.0 * count);
         // 72 KiB of (unused) dynamic LDS caps residency at 2 workgroups per CU: ~260 K pairs in flight per XCD, less than one
         // bucket, so the lines of the bucket being written stay in that XCD's 4 MiB L2 until they are complete
-        static const size_t lds_cap = [] { const char *e = getenv("DK_BUCKET_LDS"); return e ? static_cast<size_t>(atoi(e)) : size_t(72 * 1024); }();
+        const size_t lds_cap = static_cast<size_t>(DK_KNOB("DK_BUCKET_LDS", 72 * 1024));
         k_bucket_store<<<dim3(grid), dim3(RS_BLOCK), lds_cap, st>>>(scratch, count, static_cast<uint32_t>(ntiles), dst);
     }
     DK_HIP(ctx, hipGetLastError());

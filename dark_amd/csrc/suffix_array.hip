@@ -64,78 +64,6 @@ __global__ __launch_bounds__(256) void k_sym_hist(const uint8_t *__restrict__ t,
     if (sum) atomicAdd(&hist[threadIdx.x], sum);
 }
 
-// key[i] = codes of T[i .. i+spk) packed big-endian (zero padded past the end), idx[i] = i.
-// A workgroup stages the codes of its 2048 positions (+ spk look-ahead) in LDS with one table lookup per text byte; each thread
-// then builds the keys of 8 consecutive positions with a sliding window: key(i+1) = (key(i) << bits | code(T[i+spk])) & mask.
-constexpr int PK_BLOCK = 256;
-constexpr int PK_G = 8;
-constexpr int PK_TILE = PK_BLOCK * PK_G;
-constexpr int PK_AHEAD = 64 + 8;  // spk <= 64
-
-// with_prev (short-prefix path, spk * bits <= 56): the key is shifted up by 8 and its low byte carries the code of the symbol in FRONT
-// of the suffix (T[n-1] for suffix 0).  The sort leaves those bits alone; a suffix that is alone in its group after the initial sort
-// then brings its BWT symbol along and needs no gather (k_rerank_apply<true>).
-__global__ __launch_bounds__(PK_BLOCK) void k_pack_keys(const uint8_t *__restrict__ t, size_t n, const uint8_t *__restrict__ code,
-                                                         int bits, int spk, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx,
-                                                         int with_prev) {
-    __shared__ uint8_t s_code[256];
-    __shared__ __attribute__((aligned(16))) uint8_t s_c[PK_TILE + PK_AHEAD + 16];
-    __shared__ uint8_t s_before;  // code of the symbol in front of the tile's first position
-    const int tid = threadIdx.x;
-    s_code[tid] = code[tid];
-    __syncthreads();
-    const size_t b0 = static_cast<size_t>(blockIdx.x) * PK_TILE;
-    if (tid == 0) s_before = s_code[t[b0 ? b0 - 1 : n - 1]];
-    const bool aligned = (reinterpret_cast<uintptr_t>(t) & 15) == 0;
-    for (int o = tid * 16; o < PK_TILE + PK_AHEAD; o += PK_BLOCK * 16) {
-        const size_t p = b0 + o;
-        uint8_t raw[16];
-        if (aligned && p + 16 <= n) {
-            *reinterpret_cast<uint4 *>(raw) = *reinterpret_cast<const uint4 *>(t + p);
-#pragma unroll
-            for (int b = 0; b < 16; ++b) raw[b] = s_code[raw[b]];
-        } else {
-#pragma unroll
-            for (int b = 0; b < 16; ++b) raw[b] = (p + b < n) ? s_code[t[p + b]] : 0;  // zero padding past the end of the text
-        }
-        *reinterpret_cast<uint4 *>(s_c + o) = *reinterpret_cast<const uint4 *>(raw);
-    }
-    __syncthreads();
-    const int base = tid * PK_G;
-    const size_t i0 = b0 + base;
-    if (i0 >= n) return;
-    const uint64_t mask = (spk * bits >= 64) ? ~0ull : ((1ull << (spk * bits)) - 1ull);
-    uint64_t key = 0;
-    for (int j = 0; j < spk; ++j) key = (key << bits) | s_c[base + j];
-    uint64_t out[PK_G];
-    out[0] = key;
-#pragma unroll
-    for (int g = 1; g < PK_G; ++g) {
-        key = ((key << bits) | s_c[base + spk + g - 1]) & mask;
-        out[g] = key;
-    }
-    if (with_prev) {
-#pragma unroll
-        for (int g = 0; g < PK_G; ++g) out[g] = (out[g] << 8) | (base + g ? s_c[base + g - 1] : s_before);
-    }
-    if (i0 + PK_G <= n) {
-        uint4 *kp = reinterpret_cast<uint4 *>(keys + i0);
-#pragma unroll
-        for (int g = 0; g < PK_G; g += 2)
-            kp[g / 2] = make_uint4(static_cast<uint32_t>(out[g]), static_cast<uint32_t>(out[g] >> 32), static_cast<uint32_t>(out[g + 1]),
-                                   static_cast<uint32_t>(out[g + 1] >> 32));
-        uint4 *ip = reinterpret_cast<uint4 *>(idx + i0);
-        const uint32_t i32 = static_cast<uint32_t>(i0);
-        ip[0] = make_uint4(i32, i32 + 1, i32 + 2, i32 + 3);
-        ip[1] = make_uint4(i32 + 4, i32 + 5, i32 + 6, i32 + 7);
-    } else {
-        for (int g = 0; g < PK_G && i0 + g < n; ++g) {
-            keys[i0 + g] = out[g];
-            idx[i0 + g] = static_cast<uint32_t>(i0 + g);
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void k_sa_descending(uint32_t *__restrict__ sa, size_t n) {
     const size_t j = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (j < n) sa[j] = static_cast<uint32_t>(n - 1 - j);
@@ -155,9 +83,9 @@ __device__ __forceinline__ uint64_t text_key(const uint8_t *__restrict__ t, size
 // ---- how many leading symbols does the initial sort need? -------------------------------------------------------------
 // m suffixes at distinct, evenly spread (jittered) positions; for each candidate prefix length the prefixes go into one hash table
 // and equal ones are counted.  m is about 10 sqrt(n), so a sample without any equal pair says that (with high probability) fewer
-// than a few percent of ALL suffixes share their prefix of that length with another suffix: sorting by that prefix alone leaves a
-// small active list, which one text-extension round finishes.  Text-like inputs show thousands of equal pairs at every length
-// and keep the full key.
+// than a few percent of ALL suffixes share their prefix of that length with another suffix (c equal pairs: about c / 50 of them):
+// sorting by that prefix alone leaves a small active list, which one text-extension round finishes.  Text-like inputs show thousands
+// of equal pairs at every length and keep the full key.
 constexpr int PP_MAX_CAND = 4;
 struct ProbeCands { int count; int sym[PP_MAX_CAND]; };
 constexpr uint64_t PP_EMPTY = ~0ull;
@@ -342,8 +270,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
                                                             const RerankAgg *__restrict__ agg, uint32_t *__restrict__ rank,
                                                             uint32_t *__restrict__ sa, uint32_t *__restrict__ out_idx,
                                                             uint32_t *__restrict__ out_pos, uint32_t *__restrict__ out_gid,
-                                                            uint32_t *__restrict__ gstart, uint32_t *__restrict__ headpos_out,
-                                                            BwtCarry bc) {
+                                                            uint32_t *__restrict__ gstart, const uint32_t *__restrict__ mail, BwtCarry bc) {
     __shared__ uint64_t s_key[RR_TILE + 2];                       // later reused: compacted idx | pos
     __shared__ __attribute__((aligned(16))) uint32_t s_idx[RR_TILE];
     __shared__ __attribute__((aligned(16))) uint32_t s_pos[FIRST ? 4 : RR_TILE];
@@ -352,6 +279,13 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
     __shared__ uint32_t s_tmp[RR_WAVES + 1];
     const int tid = threadIdx.x;
     const size_t b0 = static_cast<size_t>(blockIdx.x) * RR_TILE;
+    if (FIRST) {
+        // The initial sort's last pass left every suffix at its slot of SA (and its symbol in L): finals need no store here, and a tile
+        // without a survivor (most tiles of random bytes and small alphabets) has nothing to compact either.
+        const uint32_t surv_before = agg[blockIdx.x].surv;
+        const uint32_t surv_after = blockIdx.x + 1 < gridDim.x ? agg[blockIdx.x + 1].surv : mail[0];
+        if (surv_before == surv_after) return;
+    }
 #pragma unroll
     for (int k = 0; k < RR_IPT; ++k) {
         const int o = k * RR_BLOCK + tid;
@@ -371,17 +305,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
             const uint64_t low8 = *reinterpret_cast<const uint64_t *>(s_low + tid * RR_IPT);
 #pragma unroll
             for (int j = 0; j < RR_IPT; ++j) sym8 |= static_cast<uint64_t>(bc.inv_code[(low8 >> (8 * j)) & 0xFFu]) << (8 * j);
-            // slot a sits at SA position a: eight finals in a row leave as one 8-byte store
-            bool all_final = a0 + RR_IPT <= count;
-#pragma unroll
-            for (int j = 0; j < RR_IPT; ++j) all_final = all_final && !((fl >> (8 * j)) & F_SURV);
-            if (all_final && ((reinterpret_cast<uintptr_t>(bc.bwt) + a0) & 7) == 0) {
-                *reinterpret_cast<uint64_t *>(bc.bwt + a0) = sym8;
-            } else {
-#pragma unroll
-                for (int j = 0; j < RR_IPT; ++j)
-                    if (a0 + j < count && !((fl >> (8 * j)) & F_SURV)) bc.bwt[a0 + j] = static_cast<uint8_t>(sym8 >> (8 * j));
-            }
+            // (a final suffix already has its symbol in L: the initial sort's last pass wrote it)
         } else if (a0 + RR_IPT <= count) {
             sym8 = *reinterpret_cast<const uint64_t *>(bc.sym_in + a0);  // a0 is a multiple of 8, the list is 256-byte aligned
         } else {
@@ -425,13 +349,14 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
         // SA position of the group's head: the head slot is in this tile (LDS) or in an earlier one (global, rare)
         const size_t hs = el >> 1;
         const uint32_t head_pos = FIRST ? static_cast<uint32_t>(hs) : (hs >= b0 ? s_pos[hs - b0] : pos_in[hs]);
-        if (headpos_out) headpos_out[a] = head_pos;  // first rerank of a large block: ranks are stored by the bucketed scatter
-        else if (rank && !(el & 1u)) rank[suffix] = head_pos;  // members of a group that kept its head keep their rank: no scatter
+        if (rank && !(el & 1u)) rank[suffix] = head_pos;  // members of a group that kept its head keep their rank: no scatter
         if (!(f & F_SURV)) {
-            sa[my_pos[j]] = suffix;  // the group is a singleton: this suffix is in its final place
-            if (bc.bwt) {
-                if (!FIRST) bc.bwt[my_pos[j]] = static_cast<uint8_t>(sym8 >> (8 * j));
-                if (suffix == 0) *bc.origin = my_pos[j];
+            if (!FIRST) {  // the group is a singleton: this suffix is in its final place (FIRST: it already stands there, see above)
+                sa[my_pos[j]] = suffix;
+                if (bc.bwt) {
+                    bc.bwt[my_pos[j]] = static_cast<uint8_t>(sym8 >> (8 * j));
+                    if (suffix == 0) *bc.origin = my_pos[j];
+                }
             }
         } else {
             if (f & F_HEAD) { gstart[eh] = base.surv + es; ++eh; }  // first slot of the surviving group in the new active list
@@ -451,12 +376,9 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
     }
 }
 
-// probe_active (first rerank only): read the number of surviving slots back after the reduce/scan phases; when it is zero the
-// initial sort already separated every suffix (random bytes, small alphabets with long keys) and nobody will ever read the
-// rank array, so the apply phase only writes SA.
+// rank == nullptr: no rank array exists yet (first rerank, text rounds)
 int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_t *pos_in, size_t count, const uint32_t *gid_in, uint32_t *rank,
-           uint32_t *sa, uint32_t *out_idx, uint32_t *out_pos, uint32_t *out_gid, uint32_t *gstart, uint32_t *headpos_out = nullptr,
-           bool probe_active = false, bool *ranks_written = nullptr, BwtCarry fb = NO_CARRY) {
+           uint32_t *sa, uint32_t *out_idx, uint32_t *out_pos, uint32_t *out_gid, uint32_t *gstart, BwtCarry fb = NO_CARRY) {
     const size_t ntiles = div_up(count, RR_TILE);
     const size_t mark = ctx->ws_mark();
     RerankAgg *agg = ctx->ws_alloc<RerankAgg>(ntiles);
@@ -470,22 +392,12 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
         LaunchScope ls(ctx, K_RERANK_SCAN, 32.0 * ntiles);
         k_rerank_scan<<<dim3(1), dim3(1024), 0, st>>>(agg, ntiles, ctx->d_mail, gstart);
     }
-    if (ranks_written) *ranks_written = true;
-    if (probe_active) {
-        DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        DK_HIP(ctx, hipStreamSynchronize(st));
-        if (ctx->h_mail[0] == 0) {  // nothing survives: ranks are dead values
-            rank = nullptr;
-            headpos_out = nullptr;
-            if (ranks_written) *ranks_written = false;
-        }
-    }
     {
         LaunchScope ls(ctx, K_RERANK_APPLY, 8.0 * count + 4.0 * count + 4.0 * count + 12.0 * count);
         if (pos_in)
-            k_rerank_apply<false><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gid_in, agg, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out, fb);
+            k_rerank_apply<false><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gid_in, agg, rank, sa, out_idx, out_pos, out_gid, gstart, ctx->d_mail, fb);
         else
-            k_rerank_apply<true><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gid_in, agg, rank, sa, out_idx, out_pos, out_gid, gstart, headpos_out, fb);
+            k_rerank_apply<true><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gid_in, agg, rank, sa, out_idx, out_pos, out_gid, gstart, ctx->d_mail, fb);
     }
     DK_HIP(ctx, hipGetLastError());
     ctx->ws_release(mark);
@@ -493,9 +405,12 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
 }
 
 // ---- big / small classification of the groups of the next round ---------------------------------------------------
-// A group of more than LS_MAX members goes through the global radix sort; bigstart[g] = number of slots in big groups
-// before group g (exclusive scan of the big sizes), bigstart[groups] = total -> mail[2].  mail[3] = number of slots in groups of more
-// than PL_MAX members (those keep the sort in general rounds; zero = the in-place rounds can take over).
+// A group of more than LS_MAX members goes through the global radix sort, in the BIG LIST: the slots of all big groups, group after
+// group.  bigidx[g] = number of big groups before group g (its dense index j), bigoff[j] = number of slots in big groups before it
+// (its offset in the big list); totals -> mail[2] (slots) and mail[4] (groups).  The global sort's key carries j, not the offset,
+// above the secondary key: j needs log2(#big groups) bits where the offset needs log2(#slots) -- two giant groups (periodic text)
+// cost ONE extra bit instead of 24, i.e. three radix passes less per round.  mail[3] = number of slots in groups of more than
+// PL_MAX members (those keep the sort in general rounds; zero = the in-place rounds can take over).
 constexpr int LS_MAX = 1024;  // general rounds: groups up to this size are sorted inside a workgroup's LDS
 constexpr int PL_MAX = 256;   // in-place (plateau) rounds need every group to have at most this many members (9-bit offsets)
 constexpr int BG_IPT = 16;
@@ -508,11 +423,11 @@ __device__ __forceinline__ uint32_t big_size(const uint32_t *__restrict__ gstart
 }
 // `groups` is read from mail[1] on the device: the host does not know it yet when these kernels are enqueued
 __global__ __launch_bounds__(256) void k_big_reduce(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ mail,
-                                                     uint32_t *__restrict__ part) {
-    __shared__ uint32_t s_w[RR_WAVES];
+                                                     uint2 *__restrict__ part) {
+    __shared__ uint32_t s_w[2][RR_WAVES];
     const size_t groups = mail[1];
     const size_t g0 = static_cast<size_t>(blockIdx.x) * BG_TILE + static_cast<size_t>(threadIdx.x) * BG_IPT;
-    uint32_t sum = 0, medium = 0;
+    uint32_t sum = 0, cnt = 0, medium = 0;
     if (g0 < groups) {
         uint32_t prev = gstart[g0];
 #pragma unroll
@@ -521,45 +436,54 @@ __global__ __launch_bounds__(256) void k_big_reduce(const uint32_t *__restrict__
             const uint32_t sz = next - prev;
             prev = next;
             sum += sz > static_cast<uint32_t>(LS_MAX) ? sz : 0u;
+            cnt += sz > static_cast<uint32_t>(LS_MAX) ? 1u : 0u;
             medium += sz > static_cast<uint32_t>(PL_MAX) ? sz : 0u;
         }
     }
     sum = wave_sum(sum);
+    cnt = wave_sum(cnt);
     medium = wave_sum(medium);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
+    if ((threadIdx.x & 63) == 0) { s_w[0][threadIdx.x >> 6] = sum; s_w[1][threadIdx.x >> 6] = cnt; }
     if ((threadIdx.x & 63) == 0 && medium) atomicAdd(const_cast<uint32_t *>(mail) + 3, medium);
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (threadIdx.x == 0) part[blockIdx.x] = make_uint2(s_w[0][0] + s_w[0][1] + s_w[0][2] + s_w[0][3], s_w[1][0] + s_w[1][1] + s_w[1][2] + s_w[1][3]);
 }
-__global__ __launch_bounds__(1024) void k_big_spine(uint32_t *__restrict__ part, size_t ntiles, uint32_t *__restrict__ mail,
-                                                    uint32_t *__restrict__ bigstart) {
+__global__ __launch_bounds__(1024) void k_big_spine(uint2 *__restrict__ part, size_t ntiles, uint32_t *__restrict__ mail) {
     __shared__ uint32_t s_tmp[16 + 1];
     const size_t per = (ntiles + 1023) / 1024;
     const size_t b0 = static_cast<size_t>(threadIdx.x) * per;
     const size_t b1 = b0 + per < ntiles ? b0 + per : ntiles;
-    uint32_t sum = 0;
-    for (size_t b = b0; b < b1; ++b) sum += part[b];
-    uint32_t total;
+    uint32_t sum = 0, cnt = 0;
+    for (size_t b = b0; b < b1; ++b) { sum += part[b].x; cnt += part[b].y; }
+    uint32_t total, total_cnt;
     uint32_t run = block_excl_sum<16>(sum, s_tmp, &total);
+    uint32_t run_cnt = block_excl_sum<16>(cnt, s_tmp, &total_cnt);
     for (size_t b = b0; b < b1; ++b) {
-        const uint32_t v = part[b];
-        part[b] = run;
-        run += v;
+        const uint2 v = part[b];
+        part[b] = make_uint2(run, run_cnt);
+        run += v.x;
+        run_cnt += v.y;
     }
-    if (threadIdx.x == 0) { mail[2] = total; bigstart[mail[1]] = total; }
+    if (threadIdx.x == 0) { mail[2] = total; mail[4] = total_cnt; }
 }
 __global__ __launch_bounds__(256) void k_big_apply(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ mail,
-                                                    const uint32_t *__restrict__ part, uint32_t *__restrict__ bigstart) {
+                                                    const uint2 *__restrict__ part, uint32_t *__restrict__ bigidx, uint32_t *__restrict__ bigoff) {
     __shared__ uint32_t s_tmp[RR_WAVES + 1];
     const size_t groups = mail[1];
     const size_t g0 = static_cast<size_t>(blockIdx.x) * BG_TILE + static_cast<size_t>(threadIdx.x) * BG_IPT;
-    uint32_t v[BG_IPT], sum = 0;
+    uint32_t v[BG_IPT], sum = 0, cnt = 0;
 #pragma unroll
-    for (int j = 0; j < BG_IPT; ++j) { v[j] = big_size(gstart, g0 + j, groups); sum += v[j]; }
-    uint32_t run = part[blockIdx.x] + block_excl_sum<RR_WAVES>(sum, s_tmp, nullptr);
+    for (int j = 0; j < BG_IPT; ++j) { v[j] = big_size(gstart, g0 + j, groups); sum += v[j]; cnt += v[j] ? 1u : 0u; }
+    const uint2 base = part[blockIdx.x];
+    uint32_t run = base.x + block_excl_sum<RR_WAVES>(sum, s_tmp, nullptr);
+    uint32_t idx = base.y + block_excl_sum<RR_WAVES>(cnt, s_tmp, nullptr);
 #pragma unroll
     for (int j = 0; j < BG_IPT; ++j) {
-        if (g0 + j < groups && v[j]) bigstart[g0 + j] = run;  // read for big groups only (k_round_local)
+        if (g0 + j < groups && v[j]) {  // read for big groups only (k_round_local)
+            bigidx[g0 + j] = idx;
+            bigoff[idx] = run;
+            ++idx;
+        }
         run += v[j];
     }
 }
@@ -628,12 +552,13 @@ __device__ __forceinline__ uint64_t text_key_coded(const uint8_t *__restrict__ t
 }
 
 // Small groups: key_out = the secondary key alone (the rerank compares keys inside an old group only).  Big groups: the global sort
-// must keep every group in its range of the big list, so its key is (offset of the group in the big list) above the secondary key,
-// cut to its leading `kb` bits when both do not fit 64 bits (text rounds: fewer symbols for the big groups); bslot remembers which
-// slot every position of the big list came from.
+// must keep every group in its range of the big list, so its key is (dense index of the group among the big groups) above the
+// secondary key, cut to its leading `kb` bits when both do not fit 64 bits (text rounds: fewer symbols for the big groups); bslot
+// remembers which slot every position of the big list came from.
 template <bool TEXT>
 __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__restrict__ act_idx, const uint32_t *__restrict__ act_gid,
-                                                          const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ bigstart,
+                                                          const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ bigidx,
+                                                          const uint32_t *__restrict__ bigoff,
                                                           const uint32_t *__restrict__ rank, uint32_t n, uint32_t h, int kbits, int kb,
                                                           size_t count, uint64_t *__restrict__ key_out, uint32_t *__restrict__ idx_out,
                                                           uint64_t *__restrict__ bkeys, uint32_t *__restrict__ bidx,
@@ -701,9 +626,9 @@ __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__rest
             idx_out[gs + before] = my_idx[k];
             if (sym_in) sym_out[gs + before] = sym_in[a];  // the symbol in front of the suffix travels with it (BwtCarry)
         } else {
-            const uint32_t bs = bigstart[g];
-            const uint32_t bo = bs + (static_cast<uint32_t>(a) - gs);
-            bkeys[bo] = (static_cast<uint64_t>(bs) << kb) | (static_cast<uint64_t>(my_r2[k]) >> (kbits - kb));
+            const uint32_t bj = bigidx[g];
+            const uint32_t bo = bigoff[bj] + (static_cast<uint32_t>(a) - gs);
+            bkeys[bo] = (static_cast<uint64_t>(bj) << kb) | (static_cast<uint64_t>(my_r2[k]) >> (kbits - kb));
             bidx[bo] = my_idx[k];
             bslot[bo] = static_cast<uint32_t>(a);
         }
@@ -900,28 +825,30 @@ __global__ __launch_bounds__(RR_BLOCK) void k_plateau_compact(const uint32_t *__
     }
 }
 
-// enqueue the classification of the groups rerank() just produced and read back (active, groups, big slots, slots in groups > PL_MAX)
-int classify_and_read(dk_ctx *ctx, size_t max_groups, uint32_t *gstart, uint32_t *bigstart, size_t *active, size_t *groups, size_t *nbig,
-                      size_t *nmedium) {
+// enqueue the classification of the groups rerank() just produced and read back (active, groups, big slots, slots in groups > PL_MAX,
+// big groups)
+int classify_and_read(dk_ctx *ctx, size_t max_groups, uint32_t *gstart, uint32_t *bigidx, uint32_t *bigoff, size_t *active, size_t *groups,
+                      size_t *nbig, size_t *nmedium, size_t *nbiggroups) {
     hipStream_t st = ctx->stream;
     const size_t mark = ctx->ws_mark();
     const size_t ntiles = div_up(max_groups + 1, BG_TILE);
-    uint32_t *part = ctx->ws_alloc<uint32_t>(ntiles);
+    uint2 *part = ctx->ws_alloc<uint2>(ntiles);
     if (!part) return DK_E_NOMEM;
     DK_HIP(ctx, hipMemsetAsync(ctx->d_mail + 3, 0, sizeof(uint32_t), st));
     {
         LaunchScope ls(ctx, K_BIG_CLASSIFY, 8.0 * max_groups);
         k_big_reduce<<<dim3(ntiles), dim3(256), 0, st>>>(gstart, ctx->d_mail, part);
-        k_big_spine<<<dim3(1), dim3(1024), 0, st>>>(part, ntiles, ctx->d_mail, bigstart);
-        k_big_apply<<<dim3(ntiles), dim3(256), 0, st>>>(gstart, ctx->d_mail, part, bigstart);
+        k_big_spine<<<dim3(1), dim3(1024), 0, st>>>(part, ntiles, ctx->d_mail);
+        k_big_apply<<<dim3(ntiles), dim3(256), 0, st>>>(gstart, ctx->d_mail, part, bigidx, bigoff);
     }
     DK_HIP(ctx, hipGetLastError());
-    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     DK_HIP(ctx, hipStreamSynchronize(st));
     *active = ctx->h_mail[0];
     *groups = ctx->h_mail[1];
     *nbig = ctx->h_mail[2];
     *nmedium = ctx->h_mail[3];
+    *nbiggroups = ctx->h_mail[4];
     ctx->ws_release(mark);
     return DK_OK;
 }
@@ -967,17 +894,18 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     uint32_t *rank = ctx->ws_alloc<uint32_t>(n);
     uint32_t *pos = ctx->ws_alloc<uint32_t>(n), *pos_alt = ctx->ws_alloc<uint32_t>(n);
     uint32_t *gid = ctx->ws_alloc<uint32_t>(n), *gid_alt = ctx->ws_alloc<uint32_t>(n);
-    uint32_t *gstart = ctx->ws_alloc<uint32_t>(n / 2 + 2), *bigstart = ctx->ws_alloc<uint32_t>(n / 2 + 2);
+    uint32_t *gstart = ctx->ws_alloc<uint32_t>(n / 2 + 2), *bigidx = ctx->ws_alloc<uint32_t>(n / 2 + 2);
+    uint32_t *bigoff = ctx->ws_alloc<uint32_t>(n / LS_MAX + 2);  // one entry per big group (more than LS_MAX members each)
     uint8_t *d_code = reinterpret_cast<uint8_t *>(ctx->d_mail + 512);
     if (!keys || !keys_alt || !keys_3 || !vals || !vals_alt || !vals_3 || !rank || !pos || !pos_alt || !gid || !gid_alt ||
-        !gstart || !bigstart)
+        !gstart || !bigidx || !bigoff)
         return DK_E_NOMEM;
     DK_HIP(ctx, hipMemcpyAsync(d_code, code, 256, hipMemcpyHostToDevice, st));
-    static const bool trace = getenv("DK_TRACE") != nullptr;
+    const bool trace = DK_KNOB("DK_TRACE", 0) != 0;
 
     // 2. how long a prefix must the initial sort cover?  DK_PREFIX: 0 = always the full key, 1 = ask the sample (default),
     //    2 = always the shortest candidate (test hook: every input then takes the short-prefix path)
-    static const int prefix_mode = [] { const char *e = getenv("DK_PREFIX"); return e ? atoi(e) : 1; }();
+    const int prefix_mode = DK_KNOB("DK_PREFIX", 1);
     int spk_sort = spk;
     if (prefix_mode != 0 && (n >= (1u << 22) || prefix_mode == 2)) {
         ProbeCands cands{0, {0, 0, 0, 0}};
@@ -1004,8 +932,12 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
             DK_HIP(ctx, hipGetLastError());
             DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 300, d_dups, PP_MAX_CAND * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             DK_HIP(ctx, hipStreamSynchronize(st));
+            // m is 10 sqrt(n), so c equal pairs in the sample say that about c / 50 of ALL suffixes share their prefix with another one.
+            // A radix pass over everything costs what a text round costs for about an eighth of it: up to 4 equal pairs (8 %) the
+            // shorter prefix wins, its survivors go through the text round
+            const uint32_t max_dups = static_cast<uint32_t>(DK_KNOB("DK_PROBE_DUPS", 4));
             for (int c = 0; c < cands.count; ++c)
-                if (ctx->h_mail[300 + c] == 0) { spk_sort = cands.sym[c]; break; }
+                if (ctx->h_mail[300 + c] <= max_dups) { spk_sort = cands.sym[c]; break; }
             if (trace)
                 fprintf(stderr, "[dk] prefix probe: %u samples, equal pairs at %d/%d/%d/%d symbols: %u %u %u %u -> sort %d of %d symbols\n", m,
                         cands.sym[0], cands.sym[1], cands.sym[2], cands.sym[3], ctx->h_mail[300], ctx->h_mail[301], ctx->h_mail[302],
@@ -1015,7 +947,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     // BWT on the way (BwtCarry): callers that want L.  The key gives up its low byte to the code of the symbol in front of the suffix, so
     // the initial sort covers at most 56 bits = seven passes instead of eight; nothing is gathered from the text afterwards.
     // DK_BWT_CARRY=0 (test hook): sort the full key and let the caller gather L from the suffix array.
-    static const bool carry_enabled = [] { const char *e = getenv("DK_BWT_CARRY"); return !(e && e[0] == '0'); }();
+    const bool carry_enabled = DK_KNOB("DK_BWT_CARRY", 1) != 0;
     const bool carry_bwt = carry_enabled && d_bwt && d_origin && bwt_written;
     const bool short_prefix = spk_sort < spk;  // the probe's verdict: few suffixes will survive the initial sort
     if (carry_bwt) spk_sort = std::min(spk_sort, 56 / bits);  // (a key merely shortened to make room for the carried byte keeps the rank path)
@@ -1033,45 +965,26 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     }
     const int key_shift = carry_bwt ? 8 : 0;
 
-    // 3. initial sort; its first pass builds the keys from the text (no key array is ever written unsorted).  DK_PACK=1: the separate
-    //    k_pack_keys kernel of round 1 (A/B and test hook)
-    static const bool pack_first = [] { const char *e = getenv("DK_PACK"); return e && e[0] == '1'; }();
-    if (pack_first || n <= 1) {
-        {
-            LaunchScope ls(ctx, K_PACK_KEYS, 1.0 * n + 12.0 * n);
-            k_pack_keys<<<dim3(div_up(n, PK_TILE)), dim3(PK_BLOCK), 0, st>>>(d_text, n, d_code, bits, spk_sort, keys, vals, carry_bwt ? 1 : 0);
-        }
-        DK_HIP(ctx, hipGetLastError());
-        DK_TRY(sort_pairs(ctx, keys, keys_alt, vals, vals_alt, n, key_shift, bits * spk_sort + key_shift));
-    } else {
+    // 3. initial sort; its first pass builds the keys from the text (no key array is ever written unsorted)
+    {
         TextKeys tk;
         tk.t = d_text; tk.n = n; tk.code = d_code; tk.bits = bits; tk.spk = spk_sort; tk.with_prev = carry_bwt ? 1 : 0;
-        DK_TRY(sort_pairs(ctx, keys, keys_alt, vals, vals_alt, n, key_shift, bits * spk_sort + key_shift, &tk));
+        // the last pass leaves every suffix at its slot of the suffix array itself (and the symbol in front of it in L): what the first
+        // rerank finds final is final where it stands -- it stores nothing for it, and a tile without a survivor costs it nothing
+        SortFinalOut fin;
+        fin.vals = d_sa;
+        if (carry_bwt) { fin.bwt = d_bwt; fin.inv_code = d_inv; fin.origin = d_origin; }
+        DK_TRY(sort_pairs(ctx, keys, keys_alt, vals, vals_alt, n, key_shift, bits * spk_sort + key_shift, &tk, &fin));
     }
 
-    // 4. first rerank (slots are SA positions).  Default: no rank array yet -- the suffixes that survive the initial sort are first
-    //    extended from the text (5a), which needs no ranks, and the rank array is built once, late, for whatever survives that (5b):
-    //    one bucketed scatter for the whole sort instead of one here plus tens of millions of random rank stores in the next round.
-    //    DK_RANKS_FIRST=1 (A/B and test hook): the rank array is built right here and the first round is a doubling round (not on the
-    //    probe's short-prefix path, which never has ranks this early).
-    size_t active = 0, groups = 0, nbig = 0, nmedium = 0;
-    static const bool bucketed = [] { const char *e = getenv("DK_BUCKETED"); return !(e && e[0] == '0'); }();
-    static const bool ranks_first_env = [] { const char *e = getenv("DK_RANKS_FIRST"); return e && e[0] == '1'; }();
-    const bool ranks_first = ranks_first_env && !short_prefix;
-    bool have_ranks = ranks_first;
+    // 4. first rerank (slots are SA positions).  No rank array yet: the suffixes that survive the initial sort are first extended from
+    //    the text (5a), which needs no ranks, and the rank array is built once, late, for whatever survives that (5b) -- one inverse
+    //    permutation for the whole sort instead of one here plus tens of millions of random rank stores in the next round.
+    size_t active = 0, groups = 0, nbig = 0, nmedium = 0, nbiggroups = 0;
+    bool have_ranks = false;
     const BwtCarry first_bc{key_shift, carry_bwt ? d_bwt : nullptr, d_inv, d_origin, nullptr, sym};
-    if (!ranks_first) {
-        DK_TRY(rerank(ctx, keys, vals, nullptr, n, nullptr, nullptr, d_sa, vals_alt, pos, gid, gstart, nullptr, false, nullptr, first_bc));
-    } else if (bucketed && n >= (1u << 22)) {
-        // rank[suffix] = head position for all n suffixes: too random for plain stores (every 4-byte store is a 64-byte line
-        // at the HBM) -> the rerank only lists the head positions, the bucketed scatter stores them XCD-locally
-        bool need_ranks = true;
-        DK_TRY(rerank(ctx, keys, vals, nullptr, n, nullptr, rank, d_sa, vals_alt, pos, gid, gstart, vals_3, true, &need_ranks, first_bc));
-        if (need_ranks) DK_TRY(scatter_u32_bucketed(ctx, vals, vals_3, n, n, keys_alt, rank));
-    } else {
-        DK_TRY(rerank(ctx, keys, vals, nullptr, n, nullptr, rank, d_sa, vals_alt, pos, gid, gstart, nullptr, true, nullptr, first_bc));
-    }
-    DK_TRY(classify_and_read(ctx, n / 2, gstart, bigstart, &active, &groups, &nbig, &nmedium));
+    DK_TRY(rerank(ctx, keys, d_sa, nullptr, n, nullptr, nullptr, d_sa, vals_alt, pos, gid, gstart, first_bc));
+    DK_TRY(classify_and_read(ctx, n / 2, gstart, bigidx, bigoff, &active, &groups, &nbig, &nmedium, &nbiggroups));
     std::swap(vals, vals_alt);  // vals = suffix indices of the active list
 
     uint64_t h = static_cast<uint64_t>(spk_sort);
@@ -1084,7 +997,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     // rounds: the big groups' keys may hold fewer symbols than the small groups' -- the depth every group is known to is the smaller).
     auto run_round = [&](int tsym, int *advanced) -> int {
         const uint32_t h_eff = static_cast<uint32_t>(std::min<uint64_t>(h, n));
-        const int bsbits = nbig > 1 ? static_cast<int>(ceil_log2_u64(nbig)) : 1;
+        const int bsbits = nbiggroups > 1 ? static_cast<int>(ceil_log2_u64(nbiggroups)) : 1;  // bits of a big group's dense index
         int kbits, kb;
         const bool raw_text = tsym > 0 && bits >= 5;  // eight raw bytes per key beat the code table unless the alphabet is small
         const int tbits = raw_text ? 8 : bits;
@@ -1105,10 +1018,10 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
             LaunchScope ls(ctx, K_ROUND_LOCAL, 8.0 * active + 4.0 * active + 12.0 * active);
             if (tsym > 0)
                 k_round_local<true><<<dim3(div_up(active, LS_TILE)), dim3(LS_BLOCK), 0, st>>>(
-                    vals, gid, gstart, bigstart, rank, static_cast<uint32_t>(n), h_eff, kbits, kb, active, keys, vals_alt, keys_alt, vals_3, bslot, ts, sym, sym_alt);
+                    vals, gid, gstart, bigidx, bigoff, rank, static_cast<uint32_t>(n), h_eff, kbits, kb, active, keys, vals_alt, keys_alt, vals_3, bslot, ts, sym, sym_alt);
             else
                 k_round_local<false><<<dim3(div_up(active, LS_TILE)), dim3(LS_BLOCK), 0, st>>>(
-                    vals, gid, gstart, bigstart, rank, static_cast<uint32_t>(n), h_eff, kbits, kb, active, keys, vals_alt, keys_alt, vals_3, bslot, ts, sym, sym_alt);
+                    vals, gid, gstart, bigidx, bigoff, rank, static_cast<uint32_t>(n), h_eff, kbits, kb, active, keys, vals_alt, keys_alt, vals_3, bslot, ts, sym, sym_alt);
         }
         DK_HIP(ctx, hipGetLastError());
         if (nbig > 0) {
@@ -1123,11 +1036,10 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
             DK_HIP(ctx, hipGetLastError());
         }
         // keys / vals_alt (/ sym_alt) now hold every group sorted by its secondary key in its own slot range
-        size_t next_active = 0, next_groups = 0, next_big = 0, next_medium = 0;
+        size_t next_active = 0, next_groups = 0, next_big = 0, next_medium = 0, next_biggroups = 0;
         const BwtCarry bc{0, carry_bwt ? d_bwt : nullptr, nullptr, d_origin, sym_alt, sym};
-        DK_TRY(rerank(ctx, keys, vals_alt, pos, active, gid, have_ranks ? rank : nullptr, d_sa, vals, pos_alt, gid_alt, gstart, nullptr, false,
-                      nullptr, bc));
-        DK_TRY(classify_and_read(ctx, active / 2, gstart, bigstart, &next_active, &next_groups, &next_big, &next_medium));
+        DK_TRY(rerank(ctx, keys, vals_alt, pos, active, gid, have_ranks ? rank : nullptr, d_sa, vals, pos_alt, gid_alt, gstart, bc));
+        DK_TRY(classify_and_read(ctx, active / 2, gstart, bigidx, bigoff, &next_active, &next_groups, &next_big, &next_medium, &next_biggroups));
         std::swap(pos, pos_alt);
         std::swap(gid, gid_alt);
         if (trace)
@@ -1137,6 +1049,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
         groups = next_groups;
         nbig = next_big;
         nmedium = next_medium;
+        nbiggroups = next_biggroups;
         ctx->stats.rounds += 1;
         return DK_OK;
     };
@@ -1145,6 +1058,9 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     //     such round only when the first left a lot (otherwise what is left are long repeats, which want doubling).
     for (int t = 0; !have_ranks && active > 0 && t < 2; ++t) {
         if (t == 1 && !short_prefix && active * 8 < n) break;
+        // mostly giant groups (periodic or run-dominated input): a text round would push them through the global sort for a few more
+        // symbols each, where a doubling round doubles the depth for the same sort -- go straight to the ranks
+        if (nbig * 2 > active) break;
         int adv = 0;
         DK_TRY(run_round(std::min(spk, 63 / bits), &adv));
         h += static_cast<uint64_t>(adv);
@@ -1165,7 +1081,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     }
 
     // 5c. doubling rounds: the general form while big groups exist, ...
-    static const bool plateau_enabled = [] { const char *e = getenv("DK_PLATEAU"); return !(e && e[0] == '0'); }();
+    const bool plateau_enabled = DK_KNOB("DK_PLATEAU", 1) != 0;
     while (active > 0 && (nmedium > 0 || !plateau_enabled)) {
         if (ctx->stats.rounds > 44) return ctx->fail(DK_E_INTERNAL, "suffix_array: no convergence after 44 rounds");
         DK_TRY(run_round(0, nullptr));

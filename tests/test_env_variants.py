@@ -1,8 +1,10 @@
-"""Alternative code paths selected by environment variables (read once per process, hence subprocesses):
-DK_ENTROPY_THREADS=2|4 (models | coder on two host threads, the four-stage pipeline of the dark model),
-DK_BUCKETED=0 / DK_XCD=0 / DK_DIGIT_PLANE=1 (plain rank scatter / plain tile order / histograms from the digit plane at every size), DK_PLATEAU=0 (general doubling rounds only, no in-place rounds),
-DK_BWT_CARRY=0 (L gathered from the suffix array instead of riding with the suffixes), DK_RANKS_FIRST=1 (rank array built straight after
-the initial sort, first round a doubling round, instead of text-extension rounds first).  Every variant must give the same bytes."""
+"""Alternative code paths selected by environment variables (read once per process, hence subprocesses).  Every variant must give
+the same bytes.
+  DK_ENTROPY_THREADS=1|2|4  host coder: one thread, models | coder on two, the four-stage pipeline of the dark model (product library)
+The device-side switches exist in the TUNING build only (dark_amd/libdark_amd_tuning.so, -DDK_TUNING: csrc/context.hpp DK_KNOB); the
+product library has them compiled in as constants:
+  DK_XCD=0 plain tile order | DK_DIGIT_PLANE=1 histograms from the digit plane at every size | DK_PLATEAU=0 general doubling rounds only
+  DK_BWT_CARRY=0 L gathered from the suffix array instead of riding with the suffixes | DK_PREFIX=0|1|2 prefix length of the initial sort"""
 import os
 import subprocess
 import sys
@@ -119,9 +121,15 @@ print("ok")
 """
 
 
-def _run(snippet, env):
+TUNING_LIB = os.path.join(ROOT, "dark_amd", "libdark_amd_tuning.so")
+
+
+def _run(snippet, env, tuning=False):
     e = dict(os.environ)
     e.update(env)
+    if tuning:
+        assert os.path.exists(TUNING_LIB), "build the tuning library: python dark_amd/build.py --tuning (__graft_entry__.build() does)"
+        e["DARK_AMD_LIB"] = TUNING_LIB
     out = subprocess.run([sys.executable, "-c", snippet % ROOT], env=e, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
@@ -138,14 +146,13 @@ def test_entropy_error_paths_return_codes(threads):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"DK_BUCKETED": "0"}, {"DK_XCD": "0"}, {"DK_DIGIT_PLANE": "1"},
-                                 {"DK_PLATEAU": "0"}, {"DK_BWT_CARRY": "0"}, {"DK_PLATEAU": "0", "DK_BWT_CARRY": "0"}, {"DK_RANKS_FIRST": "1"}, {"DK_PACK": "1"},
-                                 {"DK_RANKS_FIRST": "1", "DK_BUCKETED": "0", "DK_PLATEAU": "0"}])
+@pytest.mark.parametrize("env", [{"DK_XCD": "0"}, {"DK_DIGIT_PLANE": "1"}, {"DK_PLATEAU": "0"}, {"DK_BWT_CARRY": "0"},
+                                 {"DK_PLATEAU": "0", "DK_BWT_CARRY": "0"}])
 def test_gpu_variants_match_oracle(env):
-    _run(GPU_SNIPPET, env)
+    _run(GPU_SNIPPET, env, tuning=True)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["0", "1", "2"])
 def test_gpu_prefix_paths_match_oracle(mode):
-    _run(PREFIX_SNIPPET, {"DK_PREFIX": mode, "DK_TRACE": "1"})
+    _run(PREFIX_SNIPPET, {"DK_PREFIX": mode, "DK_TRACE": "1"}, tuning=True)

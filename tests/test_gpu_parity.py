@@ -51,6 +51,26 @@ def test_sort_pairs(ctx):
         assert first_diff(k2, keys[order]) is None, (count, lo, hi)
 
 
+def test_five_megabyte_blocks(orc):
+    """blocks above 2^22 bytes: the prefix probe picks the key length and the rank array is built through LDS windows -- text, {A,C,G,T},
+    random bytes, a period-2 block and two identical halves"""
+    from dark_amd import datagen
+    rng = np.random.default_rng(3)
+    n = 5_000_011
+    cases = [datagen.wiki_like(n, 7), datagen.acgt(n, 8), datagen.random_bytes(n, 9), np.frombuffer(b"ab" * (n // 2) + b"a", np.uint8),
+             np.concatenate([datagen.wiki_like(n // 2, 10)] * 2)]
+    with dark_amd.Context(n) as c:
+        for t in cases:
+            t = np.ascontiguousarray(t)
+            want_sa = orc.sa_sais(t)
+            got = c.suffix_array(t)
+            assert first_diff(got, want_sa) is None, first_diff(got, want_sa)
+            want_bwt, want_origin = orc.bwt_forward(t, want_sa)
+            bwt, origin = c.bwt_forward(t)
+            assert origin == want_origin and first_diff(bwt, want_bwt) is None
+    del rng
+
+
 def test_known_answers_saca_rs_411(ctx, vectors):
     # /root/reference/src/saca.rs:409-413 `detailed`, through the GPU path
     for v in vectors["reference"]["saca_rs_411_412"]:

@@ -44,6 +44,7 @@ def main():
             dist = torch.empty(n, dtype=torch.int32, device="cuda")
             rank = torch.empty(n, dtype=torch.uint8, device="cuda")
         torch.cuda.synchronize()
+        plain, kernels, passes = [], {}, 0
         for prof in (True, False):
             ctx.set_profiling(prof)
             for rep in range(reps):
@@ -56,8 +57,15 @@ def main():
                 wall = (time.perf_counter() - t0) * 1e3
                 st = ctx.stats()
                 kern = {k: round(v["ms"], 3) for k, v in st["kernels"].items()} if prof and rep == reps - 1 else ""
+                if kern:
+                    kernels = kern
+                if not prof:
+                    plain.append(st["ms_dc"] if stage == "dc" else st["ms_sa"] + st["ms_bwt"])
+                passes = st["sort_passes"]
                 print(lib, stage, kind, n, "events" if prof else "plain", "wall %.2f ms  stage %.2f ms  rounds %d" %
                       (wall, st["ms_dc"] if stage == "dc" else st["ms_sa"] + st["ms_bwt"], st["rounds"]), kern, flush=True)
+        print("SUMMARY", lib, stage, kind, n, "median plain %.3f ms" % sorted(plain)[len(plain) // 2], "passes", passes, "rounds", st["rounds"],
+              "| per kernel (one profiled step):", " ".join("%s=%.3f" % (k[2:], v) for k, v in sorted(kernels.items(), key=lambda x: -x[1])))
         print("checksum", int(out[: 1 << 22].to(torch.int64).sum()))
 
 
