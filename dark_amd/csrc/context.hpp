@@ -45,7 +45,7 @@ enum KernelSlot : int {
     K_RADIX_SORT_SMALL,
     K_RADIX_HIST_TEXT,     // k_radix_hist<false, true>: first pass, digits straight from the text (1 B per key)
     K_RADIX_SCATTER_TEXT,  // k_radix_scatter<false, true>: first pass, keys built from the text (13 B per pair)
-    K_ISA_PARTITION,       // k_isa_count + k_isa_offsets, k_isa_scatter (inverse permutation through LDS windows)
+    K_ISA_PARTITION,       // k_isa_init + k_isa_split<true> + k_isa_split<false> (inverse permutation through LDS windows)
     K_ISA_ASSEMBLE,        // k_isa_assemble
     K_SLOT_COUNT
 };
@@ -157,8 +157,9 @@ struct SortFinalOut { uint32_t *vals = nullptr; uint8_t *bwt = nullptr; const ui
 // final_out (may be null; only with the sort of more than 8192 pairs): see SortFinalOut; then `vals` / `vals_alt` are both free on return
 int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
                int begin_bit, int end_bit, const TextKeys *text = nullptr, const SortFinalOut *final_out = nullptr);
+// scratch_b (n u64, may be null): second pair buffer of the LDS-window form (inverse of a permutation of up to 2^27 entries)
 int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, size_t count, size_t limit, uint64_t *scratch,
-                         uint32_t *dst);
+                         uint64_t *scratch_b, uint32_t *dst);
 // suffix_array.hip: d_sa_out may alias nothing in the workspace; d_text is caller or ctx owned
 // d_bwt / d_origin / bwt_written (all three or none): when the sort finds the BWT on its way (short-prefix path) it writes L and the
 // origin word and sets *bwt_written; otherwise the caller gathers (bwt_forward_device does both)

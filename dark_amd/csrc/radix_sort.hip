@@ -603,71 +603,82 @@ __global__ __launch_bounds__(RS_BLOCK) void k_bucket_store(const uint64_t *__res
 // ---- inverse permutation through LDS windows: rank[sa[p]] = p for a permutation sa of 0..n-1, n <= 2^27 ------------------------------
 // The bucketed store above leans on the L2 to complete the destination lines of a 1.5 MiB window before it writes them back; the
 // counters say it does not (round 2, 1e8: WRITE_SIZE 2.27 GB for 0.40 GB of rank stores).  Here the destination is cut into windows of
-// W = 2^15 words that fit the LDS, and every word leaves for HBM exactly once, in a full coalesced line:
-//   k_isa_count    G workgroups, each over a contiguous stretch of p: how many of its sa[p] fall into each window (LDS histogram)
-//   k_isa_offsets  per window: where each workgroup's pairs start.  sa is a permutation, so window d holds EXACTLY the W suffixes
-//                  [d W, (d+1) W): its pairs occupy [d W, (d+1) W) of the pair array -- no scan over windows is needed
-//   k_isa_scatter  pairs (sa[p], p) to their window's stretch of the pair array; the order inside a window does not matter, so a
-//                  pair's place is one LDS atomic on its window's running counter (no ranking, no reordering)
-//   k_isa_assemble one workgroup per window: pairs -> LDS[suffix - d W] = p -> rank[d W ...] streamed out
-// Algorithmic bytes: 4 n + (4 n + 8 n) + (8 n + 4 n) = 28 n.
+// W = 2^wbits <= 2^15 words that fit the LDS, and every word leaves for HBM exactly once, in a full coalesced line:
+//   k_isa_split<true>   pairs (sa[p], p) into at most 64 SECTIONS of 64 windows each
+//   k_isa_split<false>  every section into its windows
+//   k_isa_assemble      one workgroup per window: pairs -> LDS[suffix - d W] = p -> rank[d W ...] streamed out
+// sa is a permutation, so a section / a window holds EXACTLY the suffixes of its range: its pairs occupy that very range of the pair
+// array.  No counting pass and no scan: a tile (4096 pairs through LDS, at most 64 bins, runs of 512 bytes on average) reserves its
+// place in every bin with one global atomic per bin on a counter that starts at the bin's first index; the order inside a bin does not
+// matter, so a pair's place inside the tile's run is one LDS atomic (no ranking, no stability).  A first attempt with ONE pass into
+// all 3052 windows (8-byte scattered stores, 512 workgroups x 3052 open lines) took 1.35 ms for that pass alone at n = 1e8.
+// Algorithmic bytes: (4 n + 8 n) + (8 n + 8 n) + (8 n + 4 n) = 40 n.
 constexpr int ISA_BLOCK = 1024;
-constexpr int ISA_WBITS = 15;                 // window = 32768 words = 128 KiB of LDS
-constexpr int ISA_MAX_WINDOWS = 4096;         // n <= 2^27
-constexpr size_t ISA_MAX_N = size_t(1) << (ISA_WBITS + 12);
+constexpr int ISA_WBITS = 15;                 // largest window = 32768 words = 128 KiB of LDS
+constexpr size_t ISA_MAX_N = size_t(1) << (ISA_WBITS + 12);  // at most 64 sections x 64 windows
+constexpr int ISP_BLOCK = 256, ISP_IPT = 16, ISP_TILE = ISP_BLOCK * ISP_IPT;  // 4096 pairs per workgroup
 
-__global__ __launch_bounds__(ISA_BLOCK) void k_isa_count(const uint32_t *__restrict__ sa, size_t n, size_t per, int wbits, uint32_t nwin,
-                                                          uint32_t *__restrict__ wg_hist) {
-    __shared__ uint32_t h[ISA_MAX_WINDOWS];
-    for (uint32_t i = threadIdx.x; i < nwin; i += ISA_BLOCK) h[i] = 0;
-    __syncthreads();
-    const size_t p0 = static_cast<size_t>(blockIdx.x) * per;  // per is a multiple of 4: the stretch starts on a 16-byte boundary
-    const size_t p1 = p0 + per < n ? p0 + per : n;
-    const size_t full = p0 + ((p1 - p0) & ~static_cast<size_t>(3));
-    for (size_t p = p0 + 4 * static_cast<size_t>(threadIdx.x); p < full; p += 4 * ISA_BLOCK) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(sa + p);
-        atomicAdd(&h[v.x >> wbits], 1u);
-        atomicAdd(&h[v.y >> wbits], 1u);
-        atomicAdd(&h[v.z >> wbits], 1u);
-        atomicAdd(&h[v.w >> wbits], 1u);
-    }
-    for (size_t p = full + threadIdx.x; p < p1; p += ISA_BLOCK) atomicAdd(&h[sa[p] >> wbits], 1u);
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nwin; i += ISA_BLOCK) wg_hist[static_cast<size_t>(blockIdx.x) * nwin + i] = h[i];
-}
-// one thread per window: counts -> start of every workgroup's pairs inside the window's stretch (which begins at d << wbits)
-__global__ __launch_bounds__(256) void k_isa_offsets(uint32_t *__restrict__ wg_hist, uint32_t nwg, uint32_t nwin, int wbits) {
+// counters[d] = first index of bin d (bins of 2^shift entries)
+__global__ __launch_bounds__(256) void k_isa_init(uint32_t *__restrict__ counters, uint32_t bins, int shift) {
     const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= nwin) return;
-    uint32_t run = d << wbits;
-#pragma unroll 8
-    for (uint32_t g = 0; g < nwg; ++g) {
-        const uint32_t c = wg_hist[static_cast<size_t>(g) * nwin + d];
-        wg_hist[static_cast<size_t>(g) * nwin + d] = run;
-        run += c;
-    }
+    if (d < bins) counters[d] = d << shift;
 }
-__global__ __launch_bounds__(ISA_BLOCK) void k_isa_scatter(const uint32_t *__restrict__ sa, size_t n, size_t per, int wbits, uint32_t nwin,
-                                                            const uint32_t *__restrict__ wg_hist, uint64_t *__restrict__ pairs) {
-    __shared__ uint32_t next[ISA_MAX_WINDOWS];
-    for (uint32_t i = threadIdx.x; i < nwin; i += ISA_BLOCK) next[i] = wg_hist[static_cast<size_t>(blockIdx.x) * nwin + i];
+
+// FIRST: item i of the tile is (sa[base + i], base + i), its bin sa >> shift.  Otherwise the items are pairs of ONE section (a tile never
+// straddles sections: a section has a multiple of 4096 entries), the bin is the window inside the section: (suffix >> shift) & 63, and
+// the counters of that section start at counters[section * 64].
+template <bool FIRST>
+__global__ __launch_bounds__(ISP_BLOCK) void k_isa_split(const uint32_t *__restrict__ sa, const uint64_t *__restrict__ pairs_in, size_t n, int shift,
+                                                          int section_shift, uint32_t *__restrict__ counters, uint64_t *__restrict__ pairs_out) {
+    __shared__ uint64_t s_item[ISP_TILE];
+    __shared__ uint32_t s_cnt[64], s_start[64], s_gbase[64];
+    const int tid = threadIdx.x;
+    const size_t base = static_cast<size_t>(blockIdx.x) * ISP_TILE;
+    const uint32_t valid = static_cast<uint32_t>(n - base < static_cast<size_t>(ISP_TILE) ? n - base : ISP_TILE);
+    uint32_t *cnt_base = FIRST ? counters : counters + ((base >> section_shift) << 6);
+    if (tid < 64) s_cnt[tid] = 0;
     __syncthreads();
-    const size_t p0 = static_cast<size_t>(blockIdx.x) * per;
-    const size_t p1 = p0 + per < n ? p0 + per : n;
-    const size_t full = p0 + ((p1 - p0) & ~static_cast<size_t>(3));
-    for (size_t p = p0 + 4 * static_cast<size_t>(threadIdx.x); p < full; p += 4 * ISA_BLOCK) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(sa + p);
-        const uint32_t s4[4] = {v.x, v.y, v.z, v.w};
+    uint64_t item[ISP_IPT];
+    uint32_t bin[ISP_IPT], r[ISP_IPT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t at = atomicAdd(&next[s4[j] >> wbits], 1u);
-            pairs[at] = (static_cast<uint64_t>(s4[j]) << 32) | static_cast<uint32_t>(p + j);
+    for (int k = 0; k < ISP_IPT; ++k) {
+        const uint32_t i = k * ISP_BLOCK + tid;
+        if (i < valid) {
+            if (FIRST) {
+                const uint32_t v = sa[base + i];
+                item[k] = (static_cast<uint64_t>(v) << 32) | static_cast<uint32_t>(base + i);
+                bin[k] = v >> shift;
+            } else {
+                item[k] = pairs_in[base + i];
+                bin[k] = (static_cast<uint32_t>(item[k] >> 32) >> shift) & 63u;
+            }
+            r[k] = atomicAdd(&s_cnt[bin[k] & 63u], 1u);
         }
     }
-    for (size_t p = full + threadIdx.x; p < p1; p += ISA_BLOCK) {
-        const uint32_t v = sa[p];
-        const uint32_t at = atomicAdd(&next[v >> wbits], 1u);
-        pairs[at] = (static_cast<uint64_t>(v) << 32) | static_cast<uint32_t>(p);
+    __syncthreads();
+    if (tid < 64) {  // one wave: exclusive scan of the 64 counts, and the tile's place in every bin (one global atomic per bin in use)
+        const uint32_t c = s_cnt[tid];
+        const uint32_t incl = wave_incl_sum(c, tid);
+        s_start[tid] = incl - c;
+        const uint32_t g = c ? atomicAdd(&cnt_base[tid], c) : 0u;
+        s_gbase[tid] = g - (incl - c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ISP_IPT; ++k) {
+        const uint32_t i = k * ISP_BLOCK + tid;
+        if (i < valid) s_item[s_start[bin[k] & 63u] + r[k]] = item[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ISP_IPT; ++k) {
+        const uint32_t q = k * ISP_BLOCK + tid;
+        if (q < valid) {
+            const uint64_t it = s_item[q];
+            const uint32_t b = FIRST ? (static_cast<uint32_t>(it >> 32) >> shift) : ((static_cast<uint32_t>(it >> 32) >> shift) & 63u);
+            const size_t at = static_cast<size_t>(s_gbase[b & 63u]) + q;
+            if (at < n) pairs_out[at] = it;  // (always true for a permutation: a guard against a corrupt input, never a wild store)
+        }
     }
 }
 __global__ __launch_bounds__(ISA_BLOCK) void k_isa_assemble(const uint64_t *__restrict__ pairs, size_t n, int wbits, uint32_t *__restrict__ rank) {
@@ -692,24 +703,31 @@ __global__ __launch_bounds__(ISA_BLOCK) void k_isa_assemble(const uint64_t *__re
     if (threadIdx.x < count - quads) rank[base + quads + threadIdx.x] = win[quads + threadIdx.x];
 }
 
-// rank[sa[p]] = p; sa must be a permutation of 0..n-1, n <= ISA_MAX_N; `scratch` holds n u64
-static int inverse_permutation_windows(dk_ctx *ctx, const uint32_t *sa, size_t n, uint64_t *scratch, uint32_t *rank) {
+// rank[sa[p]] = p; sa must be a permutation of 0..n-1, n <= ISA_MAX_N; scratch_a / scratch_b hold n u64 each
+static int inverse_permutation_windows(dk_ctx *ctx, const uint32_t *sa, size_t n, uint64_t *scratch_a, uint64_t *scratch_b, uint32_t *rank) {
     const int wbits = n > (size_t(1) << (10 + 12)) ? static_cast<int>(ceil_log2_u64(n)) - 12 : 10;  // at most 4096 windows of at least 1024 words
     const uint32_t nwin = static_cast<uint32_t>(div_up(n, size_t(1) << wbits));
-    const uint32_t nwg = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(512, div_up(n, 16 * ISA_BLOCK))));
-    const size_t per = (div_up(n, nwg) + 3) & ~static_cast<size_t>(3);
+    const bool two_levels = nwin > 64;
+    const uint32_t nsec = two_levels ? static_cast<uint32_t>(div_up(nwin, 64)) : 0;
+    const size_t ntiles = div_up(n, ISP_TILE);
     const size_t mark = ctx->ws_mark();
-    uint32_t *wg_hist = ctx->ws_alloc<uint32_t>(static_cast<size_t>(nwg) * nwin);
-    if (!wg_hist) return DK_E_NOMEM;
+    uint32_t *counters = ctx->ws_alloc<uint32_t>(64 + static_cast<size_t>(nsec ? nsec : 1) * 64);
+    if (!counters) return DK_E_NOMEM;
+    uint32_t *sec_counters = counters, *win_counters = counters + 64;
     hipStream_t st = ctx->stream;
+    uint64_t *by_window = scratch_a;
     {
-        LaunchScope ls(ctx, K_ISA_PARTITION, 4.0 * n);
-        k_isa_count<<<dim3(nwg), dim3(ISA_BLOCK), 0, st>>>(sa, n, per, wbits, nwin, wg_hist);
-        k_isa_offsets<<<dim3(div_up(nwin, 256)), dim3(256), 0, st>>>(wg_hist, nwg, nwin, wbits);
-    }
-    {
-        LaunchScope ls(ctx, K_ISA_PARTITION, 12.0 * n);
-        k_isa_scatter<<<dim3(nwg), dim3(ISA_BLOCK), 0, st>>>(sa, n, per, wbits, nwin, wg_hist, scratch);
+        LaunchScope ls(ctx, K_ISA_PARTITION, (two_levels ? 28.0 : 12.0) * n);
+        if (two_levels) {
+            k_isa_init<<<dim3(1), dim3(256), 0, st>>>(sec_counters, nsec, wbits + 6);
+            k_isa_init<<<dim3(div_up(nsec * 64, 256)), dim3(256), 0, st>>>(win_counters, nsec * 64, wbits);
+            k_isa_split<true><<<dim3(ntiles), dim3(ISP_BLOCK), 0, st>>>(sa, nullptr, n, wbits + 6, 0, sec_counters, scratch_a);
+            k_isa_split<false><<<dim3(ntiles), dim3(ISP_BLOCK), 0, st>>>(nullptr, scratch_a, n, wbits, wbits + 6, win_counters, scratch_b);
+            by_window = scratch_b;
+        } else {
+            k_isa_init<<<dim3(1), dim3(256), 0, st>>>(sec_counters, nwin, wbits);
+            k_isa_split<true><<<dim3(ntiles), dim3(ISP_BLOCK), 0, st>>>(sa, nullptr, n, wbits, 0, sec_counters, scratch_a);
+        }
     }
     {
         LaunchScope ls(ctx, K_ISA_ASSEMBLE, 12.0 * n);
@@ -717,7 +735,7 @@ static int inverse_permutation_windows(dk_ctx *ctx, const uint32_t *sa, size_t n
             return hipFuncSetAttribute(reinterpret_cast<const void *>(k_isa_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, 4 << ISA_WBITS) == hipSuccess;
         }();
         if (!lds_ok) return ctx->fail(DK_E_HIP, "k_isa_assemble: cannot reserve %d bytes of LDS", 4 << ISA_WBITS);
-        k_isa_assemble<<<dim3(nwin), dim3(ISA_BLOCK), sizeof(uint32_t) << wbits, st>>>(scratch, n, wbits, rank);
+        k_isa_assemble<<<dim3(nwin), dim3(ISA_BLOCK), sizeof(uint32_t) << wbits, st>>>(by_window, n, wbits, rank);
     }
     DK_HIP(ctx, hipGetLastError());
     ctx->ws_release(mark);
@@ -727,9 +745,9 @@ static int inverse_permutation_windows(dk_ctx *ctx, const uint32_t *sa, size_t n
 // dst[idx[i]] = val[i] (val == nullptr: = i), i < count; idx values are distinct and < limit.  `scratch` holds count u64.
 // val == nullptr with count == limit is the inverse of a permutation: up to 2^27 entries it goes through LDS windows.
 int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, size_t count, size_t limit, uint64_t *scratch,
-                         uint32_t *dst) {
+                         uint64_t *scratch_b, uint32_t *dst) {
     if (count == 0) return DK_OK;
-    if (!val && count == limit && count <= ISA_MAX_N) return inverse_permutation_windows(ctx, idx, count, scratch, dst);
+    if (!val && count == limit && count <= ISA_MAX_N && scratch_b) return inverse_permutation_windows(ctx, idx, count, scratch, scratch_b, dst);
     const size_t ntiles = div_up(count, RS_TILE);
     const size_t tiles_per_chunk = div_up(ntiles, RS_MAX_CHUNKS);
     const size_t nchunks = div_up(ntiles, tiles_per_chunk);

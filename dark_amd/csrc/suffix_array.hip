@@ -1071,7 +1071,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
             LaunchScope ls(ctx, K_PLACE_ACTIVE, 12.0 * active);
             k_place_active<<<dim3(div_up(active, 256)), dim3(256), 0, st>>>(vals, pos, active, d_sa);
         }
-        DK_TRY(scatter_u32_bucketed(ctx, d_sa, nullptr, n, n, keys_alt, rank));  // rank[SA[p]] = p
+        DK_TRY(scatter_u32_bucketed(ctx, d_sa, nullptr, n, n, keys_alt, keys_3, rank));  // rank[SA[p]] = p (keys_alt / keys_3: free between rounds)
         {
             LaunchScope ls(ctx, K_PLACE_ACTIVE, 16.0 * active);
             k_rank_active<<<dim3(div_up(active, 256)), dim3(256), 0, st>>>(vals, pos, gid, gstart, active, rank);

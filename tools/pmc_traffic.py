@@ -24,7 +24,7 @@ import sys
 GATHER_KERNELS = {"k_round_local", "k_plateau_sort", "k_plateau_ranks", "k_bwt_gather", "k_radix_scan_a", "k_radix_scan_b", "k_radix_scan_c",
                   "k_big_reduce", "k_big_spine", "k_big_apply", "k_big_back", "k_rerank_scan", "k_dc_carry_a", "k_dc_carry_b", "k_dc_carry_c",
                   "k_dc_runscan", "k_dc_sweep", "k_fill_u32", "k_place_active", "k_rank_active", "k_prefix_probe", "k_to_inplace",
-                  "k_plateau_scan", "k_radix_scan_small", "k_ibwt_walk", "k_ibwt_emit", "k_ibwt_jump", "k_isa_offsets"}
+                  "k_plateau_scan", "k_radix_scan_small", "k_ibwt_walk", "k_ibwt_emit", "k_ibwt_jump", "k_isa_init"}
 
 # dk_stats slot (dark_amd/csrc/context.hpp) of every kernel: a slot is named after its kernel, or after the common prefix of the kernels
 # one LaunchScope brackets; bench.py reports HIP-event times per slot, the rocprofv3 CSVs are per kernel
@@ -34,7 +34,7 @@ SLOT_OF = {"k_radix_hist_plane": "k_radix_hist", "k_radix_scan_small": "k_radix_
            "k_big_reduce": "k_big_classify", "k_big_spine": "k_big_classify", "k_big_apply": "k_big_classify",
            "k_rank_active": "k_place_active", "k_to_inplace": "k_plateau_ranks", "k_plateau_count": "k_plateau_ranks",
            "k_plateau_scan": "k_plateau_ranks", "k_plateau_compact": "k_plateau_ranks",
-           "k_isa_count": "k_isa_partition", "k_isa_offsets": "k_isa_partition", "k_isa_scatter": "k_isa_partition"}
+           "k_isa_init": "k_isa_partition", "k_isa_split": "k_isa_partition"}
 
 
 def short(name):
