@@ -51,8 +51,9 @@ __device__ __forceinline__ uint64_t load_key(const uint64_t *__restrict__ keys, 
 // (shifted up one byte with the code of T[i-1] below when with_prev), its value is i.  The first pass's histogram and scatter
 // kernels build the keys of their tile in LDS from n bytes of text instead of reading 12 n bytes of (key, index) pairs that a
 // separate kernel would have had to write first.
-template <class Sink>  // sink(position inside the tile, key)
-__device__ __forceinline__ void text_tile_keys(const TextKeys &tk, size_t b0, uint8_t *s_code, uint8_t *s_c, Sink &&sink) {
+// the codes of T[b0 .. b0 + RS_TILE + RS_TEXT_AHEAD) into s_c (zero past the end of the text), the code of the symbol in front of the
+// tile into s_c[RS_TILE + RS_TEXT_AHEAD]; ends with a barrier
+__device__ __forceinline__ void text_stage_codes(const TextKeys &tk, size_t b0, uint8_t *s_code, uint8_t *s_c) {
     const int tid = threadIdx.x;
     for (int i = tid; i < 256; i += RS_BLOCK) s_code[i] = tk.code[i];
     __syncthreads();
@@ -72,6 +73,12 @@ __device__ __forceinline__ void text_tile_keys(const TextKeys &tk, size_t b0, ui
         *reinterpret_cast<uint4 *>(s_c + o) = *reinterpret_cast<const uint4 *>(raw);
     }
     __syncthreads();
+}
+
+template <class Sink>  // sink(position inside the tile, key)
+__device__ __forceinline__ void text_tile_keys(const TextKeys &tk, size_t b0, uint8_t *s_code, uint8_t *s_c, Sink &&sink) {
+    const int tid = threadIdx.x;
+    text_stage_codes(tk, b0, s_code, s_c);
     const int base = tid * RS_KPT;  // RS_KPT consecutive positions per thread: a sliding window over the codes
     const int bits = tk.bits, spk = tk.spk;
     const uint64_t mask = (spk * bits >= 64) ? ~0ull : ((1ull << (spk * bits)) - 1ull);
@@ -131,9 +138,20 @@ __global__ __launch_bounds__(RS_BLOCK) void k_radix_hist(const uint64_t *__restr
     uint32_t *mine = h[tid & (RS_HCOPIES - 1)];
     const size_t base = static_cast<size_t>(blockIdx.x) * RS_TILE;
     if (TEXT) {
-        text_tile_keys(tk, base, s_code, s_c, [&](int o, uint64_t key) {
-            if (base + o < n) atomicAdd(&mine[digit_of(key, shift)], 1u);
-        });
+        // The first pass sorts by the lowest eight sorted bits of the key = the low eight bits of the packed window of spk codes: only the
+        // last ceil(8 / bits) symbols of the window reach them, so the digit slides along the staged codes in three instructions per
+        // position -- no key is built (the scatter builds them).  `shift` is the bit the sorted part of the key starts at.
+        text_stage_codes(tk, base, s_code, s_c);
+        const int p0 = tid * RS_KPT, bits = tk.bits, spk = tk.spk;
+        const int last = (8 + bits - 1) / bits < spk ? (8 + bits - 1) / bits : spk;  // symbols that reach the digit
+        const uint32_t dmask = spk * bits >= 8 ? 0xFFu : (1u << (spk * bits)) - 1u;  // (a window shorter than the digit)
+        uint32_t w = 0;
+        for (int j = spk - last; j < spk; ++j) w = (w << bits) | s_c[p0 + j];
+#pragma unroll
+        for (int g = 0; g < RS_KPT; ++g) {
+            if (base + p0 + g < n) atomicAdd(&mine[w & dmask], 1u);
+            w = (w << bits) | s_c[p0 + spk + g];
+        }
     } else if (!PAIRS && base + RS_TILE <= n) {  // full tile: two keys per 16-byte load (order inside the tile is irrelevant here)
         const uint4 *p = reinterpret_cast<const uint4 *>(keys + base);
 #pragma unroll
@@ -562,6 +580,7 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
 int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
                int begin_bit, int end_bit, const TextKeys *text, const SortFinalOut *final_out) {
     if (final_out && !text) return ctx->fail(DK_E_INTERNAL, "sort_pairs: a final destination only with the text pass");
+    if (text && begin_bit != (text->with_prev ? 8 : 0)) return ctx->fail(DK_E_INTERNAL, "sort_pairs: the text pass sorts from the key's first sorted bit");
     if (count > 0xFFFFFFFEull) return ctx->fail(DK_E_ARG, "sort_pairs: count too large");
     if (text && (count != text->n || end_bit <= begin_bit)) return ctx->fail(DK_E_INTERNAL, "sort_pairs: text pass needs at least one digit");
     if (!text && (count <= 1 || end_bit <= begin_bit)) return DK_OK;

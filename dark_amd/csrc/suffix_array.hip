@@ -158,16 +158,14 @@ __device__ __forceinline__ uint32_t slot_flag_bits(uint64_t prev, uint64_t cur, 
 }
 
 // stage keys[b0-1 .. b0+RR_TILE] into s_key[0 .. RR_TILE+1] (coalesced), then the flag bytes of the tile into s_flag
-// cmp_shift: low bits of the keys that take no part in the comparison (the previous-symbol byte of the short-prefix path); they are
-// parked in s_low (one byte per slot, s_low[o] belongs to slot b0 + o) when that is given.
+// cmp_shift: low bits of the keys that take no part in the comparison (the byte that carries the symbol in front of the suffix)
 __device__ __forceinline__ void stage_flags(const uint64_t *__restrict__ keys, size_t count, size_t b0, const uint32_t *__restrict__ gid_in,
-                                            uint64_t *s_key, uint8_t *s_flag, int cmp_shift = 0, uint8_t *s_low = nullptr) {
+                                            uint64_t *s_key, uint8_t *s_flag, int cmp_shift = 0) {
     const int tid = threadIdx.x;
     for (int o = tid; o < RR_TILE + 2; o += RR_BLOCK) {
         const size_t a = b0 + o;  // slot a - 1
         const uint64_t k = (a >= 1 && a - 1 < count) ? keys[a - 1] : 0;
         s_key[o] = k >> cmp_shift;
-        if (s_low && o >= 1 && o <= RR_TILE) s_low[o - 1] = static_cast<uint8_t>(k);
     }
     __syncthreads();
 #pragma unroll
@@ -191,16 +189,20 @@ __device__ __forceinline__ void thread_summary(uint64_t fl, size_t a0, uint32_t 
     }
 }
 
+// flags_out: one flag byte per slot (whole tiles: the array holds ntiles * RR_TILE bytes, slots past `count` get 0) -- the apply phase reads
+// these instead of the keys and group ids (8 + 4 bytes per slot) it would need to work the flags out again
 __global__ __launch_bounds__(RR_BLOCK) void k_rerank_reduce(const uint64_t *__restrict__ keys, size_t count, const uint32_t *__restrict__ gid_in,
-                                                             RerankAgg *__restrict__ agg, int cmp_shift) {
+                                                             RerankAgg *__restrict__ agg, int cmp_shift, uint8_t *__restrict__ flags_out) {
     __shared__ uint64_t s_key[RR_TILE + 2];
     __shared__ __attribute__((aligned(8))) uint8_t s_flag[RR_TILE];
     __shared__ uint32_t s_red[3][RR_WAVES];
     const size_t b0 = static_cast<size_t>(blockIdx.x) * RR_TILE;
     stage_flags(keys, count, b0, gid_in, s_key, s_flag, cmp_shift);
     const size_t a0 = b0 + static_cast<size_t>(threadIdx.x) * RR_IPT;
+    const uint64_t fl8 = *reinterpret_cast<const uint64_t *>(s_flag + threadIdx.x * RR_IPT);
+    *reinterpret_cast<uint64_t *>(flags_out + a0) = fl8;
     uint32_t ns, nh, lh;
-    thread_summary(*reinterpret_cast<const uint64_t *>(s_flag + threadIdx.x * RR_IPT), a0, ns, nh, lh);
+    thread_summary(fl8, a0, ns, nh, lh);
     ns = wave_sum(ns);
     nh = wave_sum(nh);
     lh = wave_max(lh);
@@ -227,7 +229,8 @@ __global__ __launch_bounds__(1024) void k_rerank_scan(RerankAgg *__restrict__ ag
     const size_t b0 = static_cast<size_t>(tid) * per;
     const size_t b1 = b0 + per < ntiles ? b0 + per : ntiles;
     uint32_t ns = 0, nh = 0, lh = 0;
-    for (size_t b = b0; b < b1; ++b) {
+#pragma unroll 16
+    for (size_t b = b0; b < b1; ++b) {  // (a thread's stretch is contiguous: unrolled, its loads are in flight together)
         const RerankAgg r = agg[b];
         ns += r.surv;
         nh += r.heads;
@@ -237,6 +240,7 @@ __global__ __launch_bounds__(1024) void k_rerank_scan(RerankAgg *__restrict__ ag
     uint32_t es = block_excl_sum<16>(ns, s_tmp, &tot_s);
     uint32_t eh = block_excl_sum<16>(nh, s_tmp, &tot_h);
     uint32_t el = block_excl_max<16>(lh, s_tmp, nullptr);
+#pragma unroll 16
     for (size_t b = b0; b < b1; ++b) {
         const RerankAgg r = agg[b];
         agg[b] = RerankAgg{es, eh, el, 0};
@@ -262,20 +266,19 @@ struct BwtCarry {
 constexpr BwtCarry NO_CARRY{0, nullptr, nullptr, nullptr, nullptr, nullptr};
 
 // pos_in == nullptr means slot a sits at SA position a (first rerank, straight after the initial sort).
-// All tile inputs arrive through LDS with lane-contiguous loads; the compacted outputs leave through LDS the same way.
-// FIRST = (pos_in == nullptr): no position array to stage, 8 KiB of LDS less -> more workgroups per CU for the largest launch
+// The flags come from k_rerank_reduce's byte array; the tile's lists arrive through LDS with lane-contiguous loads, the compacted outputs
+// leave through LDS the same way.  FIRST = (pos_in == nullptr): no position array to stage -> more workgroups per CU for the largest launch
 template <bool FIRST>
-__global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx,
-                                                            const uint32_t *__restrict__ pos_in, size_t count, const uint32_t *__restrict__ gid_in,
+__global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ idx,
+                                                            const uint32_t *__restrict__ pos_in, size_t count,
                                                             const RerankAgg *__restrict__ agg, uint32_t *__restrict__ rank,
                                                             uint32_t *__restrict__ sa, uint32_t *__restrict__ out_idx,
                                                             uint32_t *__restrict__ out_pos, uint32_t *__restrict__ out_gid,
                                                             uint32_t *__restrict__ gstart, const uint32_t *__restrict__ mail, BwtCarry bc) {
-    __shared__ uint64_t s_key[RR_TILE + 2];                       // later reused: compacted idx | pos
+    __shared__ __attribute__((aligned(16))) uint32_t s_out[2 * RR_TILE];  // compacted idx | pos
     __shared__ __attribute__((aligned(16))) uint32_t s_idx[RR_TILE];
     __shared__ __attribute__((aligned(16))) uint32_t s_pos[FIRST ? 4 : RR_TILE];
-    __shared__ __attribute__((aligned(8))) uint8_t s_flag[RR_TILE];
-    __shared__ __attribute__((aligned(8))) uint8_t s_low[RR_TILE];  // bc.bwt: FIRST: previous-symbol codes of the tile; later: compacted symbols
+    __shared__ __attribute__((aligned(8))) uint8_t s_osym[RR_TILE];        // compacted symbols
     __shared__ uint32_t s_tmp[RR_WAVES + 1];
     const int tid = threadIdx.x;
     const size_t b0 = static_cast<size_t>(blockIdx.x) * RR_TILE;
@@ -295,23 +298,19 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
             if (!FIRST) s_pos[o] = pos_in[a];
         }
     }
-    // ends with a barrier: s_idx / s_pos (/ s_low) are visible, s_key is free
-    stage_flags(keys, count, b0, gid_in, s_key, s_flag, FIRST ? bc.cmp_shift : 0, (FIRST && bc.bwt) ? s_low : nullptr);
     const size_t a0 = b0 + static_cast<size_t>(tid) * RR_IPT;
-    const uint64_t fl = *reinterpret_cast<const uint64_t *>(s_flag + tid * RR_IPT);
+    const uint64_t fl = *reinterpret_cast<const uint64_t *>(flags + a0);  // whole tiles are stored: zero past `count`
     uint64_t sym8 = 0;  // bc.bwt: the symbols in front of this thread's eight suffixes
     if (bc.bwt && a0 < count) {
-        if (FIRST) {
-            const uint64_t low8 = *reinterpret_cast<const uint64_t *>(s_low + tid * RR_IPT);
-#pragma unroll
-            for (int j = 0; j < RR_IPT; ++j) sym8 |= static_cast<uint64_t>(bc.inv_code[(low8 >> (8 * j)) & 0xFFu]) << (8 * j);
-            // (a final suffix already has its symbol in L: the initial sort's last pass wrote it)
-        } else if (a0 + RR_IPT <= count) {
-            sym8 = *reinterpret_cast<const uint64_t *>(bc.sym_in + a0);  // a0 is a multiple of 8, the list is 256-byte aligned
+        // FIRST: the initial sort's last pass wrote L[slot] for every slot: that is the symbol in front of the suffix standing there
+        const uint8_t *src = FIRST ? bc.bwt : bc.sym_in;
+        if (a0 + RR_IPT <= count && ((reinterpret_cast<uintptr_t>(src) + a0) & 7) == 0) {
+            sym8 = *reinterpret_cast<const uint64_t *>(src + a0);
         } else {
-            for (int j = 0; j < RR_IPT && a0 + j < count; ++j) sym8 |= static_cast<uint64_t>(bc.sym_in[a0 + j]) << (8 * j);
+            for (int j = 0; j < RR_IPT && a0 + j < count; ++j) sym8 |= static_cast<uint64_t>(src[a0 + j]) << (8 * j);
         }
     }
+    __syncthreads();  // s_idx / s_pos are visible
     uint32_t ns, nh, lh;
     thread_summary(fl, a0, ns, nh, lh);
     const RerankAgg base = agg[blockIdx.x];
@@ -320,8 +319,8 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
     uint32_t eh = base.heads + block_excl_sum<RR_WAVES>(nh, s_tmp, nullptr);
     uint32_t el = block_excl_max<RR_WAVES>(lh, s_tmp, nullptr);
     el = el > base.last_head ? el : base.last_head;
-    uint32_t *s_oidx = reinterpret_cast<uint32_t *>(s_key);
-    uint32_t *s_opos = s_oidx + RR_TILE;
+    uint32_t *s_oidx = s_out;
+    uint32_t *s_opos = s_out + RR_TILE;
     uint32_t my_idx[RR_IPT], my_pos[RR_IPT];
     {
         const uint4 *pi = reinterpret_cast<const uint4 *>(s_idx + tid * RR_IPT);
@@ -336,9 +335,8 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint64_t *__res
             my_pos[0] = p0.x; my_pos[1] = p0.y; my_pos[2] = p0.z; my_pos[3] = p0.w; my_pos[4] = p1.x; my_pos[5] = p1.y; my_pos[6] = p1.z; my_pos[7] = p1.w;
         }
     }
-    __syncthreads();              // every thread holds its slice of s_idx (and of s_low) in registers:
-    uint32_t *s_ogid = s_idx;     // the array now collects the compacted group ids (37 KiB of LDS: four workgroups per CU)
-    uint8_t *s_osym = s_low;      // and this one the compacted symbols
+    __syncthreads();              // every thread holds its slice of s_idx in registers:
+    uint32_t *s_ogid = s_idx;     // the array now collects the compacted group ids
 #pragma unroll
     for (int j = 0; j < RR_IPT; ++j) {
         const size_t a = a0 + j;
@@ -382,22 +380,24 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
     const size_t ntiles = div_up(count, RR_TILE);
     const size_t mark = ctx->ws_mark();
     RerankAgg *agg = ctx->ws_alloc<RerankAgg>(ntiles);
-    if (!agg) return DK_E_NOMEM;
+    uint8_t *flags = ctx->ws_alloc<uint8_t>(ntiles * RR_TILE);  // whole tiles
+    if (!agg || !flags) return DK_E_NOMEM;
     hipStream_t st = ctx->stream;
     {
-        LaunchScope ls(ctx, K_RERANK_REDUCE, 8.0 * count);
-        k_rerank_reduce<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, count, gid_in, agg, pos_in ? 0 : fb.cmp_shift);
+        LaunchScope ls(ctx, K_RERANK_REDUCE, (8.0 + (gid_in ? 4.0 : 0.0) + 1.0) * count);
+        k_rerank_reduce<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, count, gid_in, agg, pos_in ? 0 : fb.cmp_shift, flags);
     }
     {
         LaunchScope ls(ctx, K_RERANK_SCAN, 32.0 * ntiles);
         k_rerank_scan<<<dim3(1), dim3(1024), 0, st>>>(agg, ntiles, ctx->d_mail, gstart);
     }
     {
-        LaunchScope ls(ctx, K_RERANK_APPLY, 8.0 * count + 4.0 * count + 4.0 * count + 12.0 * count);
+        // flags 1 + suffix 4 (+ position 4) + symbol 1 in; SA 4 + L 1 for finals or 13 compacted out (FIRST: finals already stand in SA / L)
+        LaunchScope ls(ctx, K_RERANK_APPLY, (pos_in ? 10.0 + 9.0 : 6.0 + 13.0) * count);
         if (pos_in)
-            k_rerank_apply<false><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gid_in, agg, rank, sa, out_idx, out_pos, out_gid, gstart, ctx->d_mail, fb);
+            k_rerank_apply<false><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(flags, idx, pos_in, count, agg, rank, sa, out_idx, out_pos, out_gid, gstart, ctx->d_mail, fb);
         else
-            k_rerank_apply<true><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, idx, pos_in, count, gid_in, agg, rank, sa, out_idx, out_pos, out_gid, gstart, ctx->d_mail, fb);
+            k_rerank_apply<true><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(flags, idx, pos_in, count, agg, rank, sa, out_idx, out_pos, out_gid, gstart, ctx->d_mail, fb);
     }
     DK_HIP(ctx, hipGetLastError());
     ctx->ws_release(mark);
