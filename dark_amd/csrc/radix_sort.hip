@@ -521,10 +521,11 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
     uint32_t *tile_hist = ctx->ws_alloc<uint32_t>(ntiles * 256);
     uint32_t *chunk_sum = ctx->ws_alloc<uint32_t>(nchunks * 256);
     // digit plane: every scatter but the last leaves the next pass's digits behind, one byte per pair.  The histograms get 2x faster,
-    // the scatters 15 % slower (the plane's 16-byte runs cost as many L2 write requests as the 64-byte runs of the values).  Measured
-    // net gain: 1.4 % at 1e8 pairs (inside the box-to-box variation), 2 % at 2^28, 3.7 % at 2^30: on from 2^28 pairs.
+    // the scatters 10 % slower (the plane's 16-byte runs cost as many L2 write requests as the 64-byte runs of the values).  Net gain,
+    // round 3: 2.7 % of the whole suffix sort at 1e8 pairs (12.07 -> 11.74 ms), 1.8 % at 2^28; on from 2^26 pairs, where the keys
+    // (8 bytes per pair) no longer fit the 256 MiB Infinity Cache.
     const int plane_mode = DK_KNOB("DK_DIGIT_PLANE", -1);  // tuning build: 1 / 0 = always (from 2^20 pairs) / never
-    const size_t plane_from = plane_mode == 1 ? (size_t(1) << 20) : (size_t(1) << 28);
+    const size_t plane_from = plane_mode == 1 ? (size_t(1) << 20) : (size_t(1) << 26);
     uint8_t *plane = plane_mode != 0 && end_bit - begin_bit > 8 && count >= plane_from ? ctx->ws_try_alloc<uint8_t>(count) : nullptr;  // optional: the sort runs without it
     if (!tile_hist || !chunk_sum) return DK_E_NOMEM;
     hipStream_t st = ctx->stream;

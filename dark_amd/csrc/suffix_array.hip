@@ -251,6 +251,64 @@ __global__ __launch_bounds__(1024) void k_rerank_scan(RerankAgg *__restrict__ ag
     if (tid == 0) { mail[0] = tot_s; mail[1] = tot_h; gstart[tot_h] = tot_s; }  // sentinel: one past the last group
 }
 
+// The same scan for many tiles, in three phases over chunks of RS_CHUNK tiles (one workgroup reads at the rate of one CU: 524 288
+// aggregates of a 2^30-byte block took it 0.4 ms): A reduces every chunk, B (one workgroup) scans the chunk aggregates, C scans inside
+// every chunk from its chunk's base.
+constexpr int RSC_CHUNK = 1024, RSC_IPT = 4;  // tiles per chunk = 256 threads x 4
+__global__ __launch_bounds__(256) void k_rerank_scan_a(const RerankAgg *__restrict__ agg, size_t ntiles, RerankAgg *__restrict__ chunk) {
+    __shared__ uint32_t s_red[3][RR_WAVES];
+    const size_t b0 = static_cast<size_t>(blockIdx.x) * RSC_CHUNK + static_cast<size_t>(threadIdx.x) * RSC_IPT;
+    uint32_t ns = 0, nh = 0, lh = 0;
+#pragma unroll
+    for (int j = 0; j < RSC_IPT; ++j) {
+        if (b0 + j < ntiles) {
+            const RerankAgg r = agg[b0 + j];
+            ns += r.surv;
+            nh += r.heads;
+            lh = lh > r.last_head ? lh : r.last_head;
+        }
+    }
+    ns = wave_sum(ns);
+    nh = wave_sum(nh);
+    lh = wave_max(lh);
+    if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = ns; s_red[1][threadIdx.x >> 6] = nh; s_red[2][threadIdx.x >> 6] = lh; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        RerankAgg r{0, 0, 0, 0};
+        for (int w = 0; w < RR_WAVES; ++w) {
+            r.surv += s_red[0][w];
+            r.heads += s_red[1][w];
+            r.last_head = r.last_head > s_red[2][w] ? r.last_head : s_red[2][w];
+        }
+        chunk[blockIdx.x] = r;
+    }
+}
+__global__ __launch_bounds__(256) void k_rerank_scan_c(RerankAgg *__restrict__ agg, size_t ntiles, const RerankAgg *__restrict__ chunk) {
+    __shared__ uint32_t s_tmp[RR_WAVES + 1];
+    const size_t b0 = static_cast<size_t>(blockIdx.x) * RSC_CHUNK + static_cast<size_t>(threadIdx.x) * RSC_IPT;
+    RerankAgg r[RSC_IPT];
+    uint32_t ns = 0, nh = 0, lh = 0;
+#pragma unroll
+    for (int j = 0; j < RSC_IPT; ++j) {
+        r[j] = b0 + j < ntiles ? agg[b0 + j] : RerankAgg{0, 0, 0, 0};
+        ns += r[j].surv;
+        nh += r[j].heads;
+        lh = lh > r[j].last_head ? lh : r[j].last_head;
+    }
+    const RerankAgg base = chunk[blockIdx.x];  // exclusive over the chunks (phase B)
+    uint32_t es = base.surv + block_excl_sum<RR_WAVES>(ns, s_tmp, nullptr);
+    uint32_t eh = base.heads + block_excl_sum<RR_WAVES>(nh, s_tmp, nullptr);
+    uint32_t el = block_excl_max<RR_WAVES>(lh, s_tmp, nullptr);
+    el = el > base.last_head ? el : base.last_head;
+#pragma unroll
+    for (int j = 0; j < RSC_IPT; ++j) {
+        if (b0 + j < ntiles) agg[b0 + j] = RerankAgg{es, eh, el, 0};
+        es += r[j].surv;
+        eh += r[j].heads;
+        el = el > r[j].last_head ? el : r[j].last_head;
+    }
+}
+
 // BWT on the way.  When the caller wants L, the initial keys carry, below the sorted bits, the code of the symbol in FRONT of the suffix
 // (cmp_shift = 8 low bits that take no part in any comparison).  The first rerank turns it into the symbol itself: a suffix that is
 // final writes L[its SA position] (and, for suffix 0, the origin); a suffix that stays active takes the symbol along in a byte list
@@ -389,7 +447,16 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
     }
     {
         LaunchScope ls(ctx, K_RERANK_SCAN, 32.0 * ntiles);
-        k_rerank_scan<<<dim3(1), dim3(1024), 0, st>>>(agg, ntiles, ctx->d_mail, gstart);
+        if (ntiles <= 4 * RSC_CHUNK) {
+            k_rerank_scan<<<dim3(1), dim3(1024), 0, st>>>(agg, ntiles, ctx->d_mail, gstart);
+        } else {  // phase B is the one-workgroup scan itself, over the chunk aggregates (totals -> mail, sentinel -> gstart)
+            const size_t nchunks = div_up(ntiles, RSC_CHUNK);
+            RerankAgg *chunk = ctx->ws_alloc<RerankAgg>(nchunks);
+            if (!chunk) return DK_E_NOMEM;
+            k_rerank_scan_a<<<dim3(nchunks), dim3(256), 0, st>>>(agg, ntiles, chunk);
+            k_rerank_scan<<<dim3(1), dim3(1024), 0, st>>>(chunk, nchunks, ctx->d_mail, gstart);
+            k_rerank_scan_c<<<dim3(nchunks), dim3(256), 0, st>>>(agg, ntiles, chunk);
+        }
     }
     {
         // flags 1 + suffix 4 (+ position 4) + symbol 1 in; SA 4 + L 1 for finals or 13 compacted out (FIRST: finals already stand in SA / L)
@@ -421,14 +488,25 @@ __device__ __forceinline__ uint32_t big_size(const uint32_t *__restrict__ gstart
     const uint32_t sz = gstart[g + 1] - gstart[g];
     return sz > static_cast<uint32_t>(LS_MAX) ? sz : 0u;
 }
-// `groups` is read from mail[1] on the device: the host does not know it yet when these kernels are enqueued
+// `groups` is read from mail[1] on the device: the host does not know it yet when these kernels are enqueued.  The grid is fixed
+// (BG_GRID workgroups); every workgroup takes a contiguous stretch of tiles of groups, so that `part` has BG_GRID entries whatever n.
+constexpr int BG_GRID = 1024;
+__device__ __forceinline__ void big_stretch(size_t groups, size_t *t0, size_t *t1) {
+    const size_t ntiles = (groups + BG_TILE - 1) / BG_TILE;
+    const size_t per = (ntiles + BG_GRID - 1) / BG_GRID;
+    *t0 = static_cast<size_t>(blockIdx.x) * per;
+    *t1 = *t0 + per < ntiles ? *t0 + per : ntiles;
+}
 __global__ __launch_bounds__(256) void k_big_reduce(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ mail,
                                                      uint2 *__restrict__ part) {
     __shared__ uint32_t s_w[2][RR_WAVES];
     const size_t groups = mail[1];
-    const size_t g0 = static_cast<size_t>(blockIdx.x) * BG_TILE + static_cast<size_t>(threadIdx.x) * BG_IPT;
+    size_t t0, t1;
+    big_stretch(groups, &t0, &t1);
     uint32_t sum = 0, cnt = 0, medium = 0;
-    if (g0 < groups) {
+    for (size_t t = t0; t < t1; ++t) {
+        const size_t g0 = t * BG_TILE + static_cast<size_t>(threadIdx.x) * BG_IPT;
+        if (g0 >= groups) continue;
         uint32_t prev = gstart[g0];
 #pragma unroll
         for (int j = 0; j < BG_IPT && g0 + j < groups; ++j) {
@@ -448,43 +526,42 @@ __global__ __launch_bounds__(256) void k_big_reduce(const uint32_t *__restrict__
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = make_uint2(s_w[0][0] + s_w[0][1] + s_w[0][2] + s_w[0][3], s_w[1][0] + s_w[1][1] + s_w[1][2] + s_w[1][3]);
 }
-__global__ __launch_bounds__(1024) void k_big_spine(uint2 *__restrict__ part, size_t ntiles, uint32_t *__restrict__ mail) {
+__global__ __launch_bounds__(BG_GRID) void k_big_spine(uint2 *__restrict__ part, uint32_t *__restrict__ mail) {
     __shared__ uint32_t s_tmp[16 + 1];
-    const size_t per = (ntiles + 1023) / 1024;
-    const size_t b0 = static_cast<size_t>(threadIdx.x) * per;
-    const size_t b1 = b0 + per < ntiles ? b0 + per : ntiles;
-    uint32_t sum = 0, cnt = 0;
-    for (size_t b = b0; b < b1; ++b) { sum += part[b].x; cnt += part[b].y; }
+    const uint2 v = part[threadIdx.x];
     uint32_t total, total_cnt;
-    uint32_t run = block_excl_sum<16>(sum, s_tmp, &total);
-    uint32_t run_cnt = block_excl_sum<16>(cnt, s_tmp, &total_cnt);
-    for (size_t b = b0; b < b1; ++b) {
-        const uint2 v = part[b];
-        part[b] = make_uint2(run, run_cnt);
-        run += v.x;
-        run_cnt += v.y;
-    }
+    const uint32_t run = block_excl_sum<BG_GRID / 64>(v.x, s_tmp, &total);
+    const uint32_t run_cnt = block_excl_sum<BG_GRID / 64>(v.y, s_tmp, &total_cnt);
+    part[threadIdx.x] = make_uint2(run, run_cnt);
     if (threadIdx.x == 0) { mail[2] = total; mail[4] = total_cnt; }
 }
 __global__ __launch_bounds__(256) void k_big_apply(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ mail,
                                                     const uint2 *__restrict__ part, uint32_t *__restrict__ bigidx, uint32_t *__restrict__ bigoff) {
     __shared__ uint32_t s_tmp[RR_WAVES + 1];
     const size_t groups = mail[1];
-    const size_t g0 = static_cast<size_t>(blockIdx.x) * BG_TILE + static_cast<size_t>(threadIdx.x) * BG_IPT;
-    uint32_t v[BG_IPT], sum = 0, cnt = 0;
+    size_t t0, t1;
+    big_stretch(groups, &t0, &t1);
+    uint2 base = part[blockIdx.x];
+    if (base.x == (blockIdx.x + 1 < gridDim.x ? part[blockIdx.x + 1].x : mail[2])) return;  // no big group in this stretch
+    for (size_t t = t0; t < t1; ++t) {
+        const size_t g0 = t * BG_TILE + static_cast<size_t>(threadIdx.x) * BG_IPT;
+        uint32_t v[BG_IPT], sum = 0, cnt = 0;
 #pragma unroll
-    for (int j = 0; j < BG_IPT; ++j) { v[j] = big_size(gstart, g0 + j, groups); sum += v[j]; cnt += v[j] ? 1u : 0u; }
-    const uint2 base = part[blockIdx.x];
-    uint32_t run = base.x + block_excl_sum<RR_WAVES>(sum, s_tmp, nullptr);
-    uint32_t idx = base.y + block_excl_sum<RR_WAVES>(cnt, s_tmp, nullptr);
+        for (int j = 0; j < BG_IPT; ++j) { v[j] = big_size(gstart, g0 + j, groups); sum += v[j]; cnt += v[j] ? 1u : 0u; }
+        uint32_t tile_sum, tile_cnt;
+        uint32_t run = base.x + block_excl_sum<RR_WAVES>(sum, s_tmp, &tile_sum);
+        uint32_t idx = base.y + block_excl_sum<RR_WAVES>(cnt, s_tmp, &tile_cnt);
 #pragma unroll
-    for (int j = 0; j < BG_IPT; ++j) {
-        if (g0 + j < groups && v[j]) {  // read for big groups only (k_round_local)
-            bigidx[g0 + j] = idx;
-            bigoff[idx] = run;
-            ++idx;
+        for (int j = 0; j < BG_IPT; ++j) {
+            if (g0 + j < groups && v[j]) {  // read for big groups only (k_round_local)
+                bigidx[g0 + j] = idx;
+                bigoff[idx] = run;
+                ++idx;
+            }
+            run += v[j];
         }
-        run += v[j];
+        base.x += tile_sum;
+        base.y += tile_cnt;
     }
 }
 
@@ -831,15 +908,15 @@ int classify_and_read(dk_ctx *ctx, size_t max_groups, uint32_t *gstart, uint32_t
                       size_t *nbig, size_t *nmedium, size_t *nbiggroups) {
     hipStream_t st = ctx->stream;
     const size_t mark = ctx->ws_mark();
-    const size_t ntiles = div_up(max_groups + 1, BG_TILE);
-    uint2 *part = ctx->ws_alloc<uint2>(ntiles);
+    (void)max_groups;
+    uint2 *part = ctx->ws_alloc<uint2>(BG_GRID);
     if (!part) return DK_E_NOMEM;
     DK_HIP(ctx, hipMemsetAsync(ctx->d_mail + 3, 0, sizeof(uint32_t), st));
     {
         LaunchScope ls(ctx, K_BIG_CLASSIFY, 8.0 * max_groups);
-        k_big_reduce<<<dim3(ntiles), dim3(256), 0, st>>>(gstart, ctx->d_mail, part);
-        k_big_spine<<<dim3(1), dim3(1024), 0, st>>>(part, ntiles, ctx->d_mail);
-        k_big_apply<<<dim3(ntiles), dim3(256), 0, st>>>(gstart, ctx->d_mail, part, bigidx, bigoff);
+        k_big_reduce<<<dim3(BG_GRID), dim3(256), 0, st>>>(gstart, ctx->d_mail, part);
+        k_big_spine<<<dim3(1), dim3(BG_GRID), 0, st>>>(part, ctx->d_mail);
+        k_big_apply<<<dim3(BG_GRID), dim3(256), 0, st>>>(gstart, ctx->d_mail, part, bigidx, bigoff);
     }
     DK_HIP(ctx, hipGetLastError());
     DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
