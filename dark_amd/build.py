@@ -23,7 +23,7 @@ def _deps():
 
 SO_TUNING = os.path.join(HERE, "libdark_amd_tuning.so")
 # sources that hold A/B switches (DK_KNOB, csrc/context.hpp): the tuning build compiles them with -DDK_TUNING, everything else is shared
-TUNING_SOURCES = ("context.cpp", "radix_sort.hip", "suffix_array.hip")
+TUNING_SOURCES = ("context.cpp", "radix_sort.hip", "suffix_array.hip", "bwt.hip")
 
 
 def build(force=False, verbose=False, tuning=False):

@@ -171,9 +171,14 @@ __device__ __forceinline__ uint32_t splitter_id(uint32_t p, uint32_t S, uint32_t
 
 // Text step k visits position cur_k: cur_0 = origin, cur_{k+1} = psi[cur_k]... with the reference's convention the
 // text symbol k is L[psi[cur_k]], and the last symbol is L[origin] when psi hits END.
+// rec (may be null): the walk also RECORDS the symbols it passes -- the first IB_REC of them, eight at a time, into the splitter's own
+// IB_REC-byte stretch of `rec` -- and the position a longer walk stands at after IB_REC steps (resume); k_ibwt_copy then writes the text
+// from these records instead of walking the successor table a second time (one random 64-byte line per text byte saved).
+constexpr uint32_t IB_REC = 256;
 __global__ __launch_bounds__(256) void k_ibwt_walk(const uint64_t *__restrict__ psi, uint32_t n, uint32_t origin, uint32_t S,
                                                     uint32_t nreg, uint32_t nsplit, uint32_t *__restrict__ nxt,
-                                                    uint32_t *__restrict__ len) {
+                                                    uint32_t *__restrict__ len, uint32_t *__restrict__ len_keep, uint8_t *__restrict__ rec,
+                                                    uint32_t *__restrict__ resume) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsplit) return;
     uint32_t cur;
@@ -181,19 +186,29 @@ __global__ __launch_bounds__(256) void k_ibwt_walk(const uint64_t *__restrict__ 
         cur = origin;  // only exists when origin % S != 0
     } else {
         cur = s * S;
-        if (cur >= n) { nxt[s] = IB_END; len[s] = 0; return; }
+        if (cur >= n) { nxt[s] = IB_END; len[s] = 0; if (len_keep) len_keep[s] = 0; return; }
     }
     uint32_t steps = 0, to = IB_END;
+    uint64_t acc = 0;
+    uint64_t *out = rec ? reinterpret_cast<uint64_t *>(rec + static_cast<size_t>(s) * IB_REC) : nullptr;
     for (;;) {
-        const uint32_t p = static_cast<uint32_t>(psi[cur]);
+        const uint64_t e = psi[cur];
+        const uint32_t p = static_cast<uint32_t>(e);
+        if (rec && steps < IB_REC) {
+            acc |= (e >> 32 & 0xFFull) << (8 * (steps & 7u));  // the symbol this step emits
+            if ((steps & 7u) == 7u) { out[steps >> 3] = acc; acc = 0; }
+        }
         ++steps;  // this step emits one text symbol
         if (p == IB_END) break;
         if (is_splitter(p, S, origin)) { to = splitter_id(p, S, origin, nreg); break; }
         cur = p;
+        if (rec && steps == IB_REC) resume[s] = cur;  // where a walk longer than the record goes on
         if (steps > n) break;  // corrupt input: never spin
     }
+    if (rec && steps < IB_REC && (steps & 7u)) out[steps >> 3] = acc;  // the last, partial word (the stretch is the splitter's own)
     nxt[s] = to;
     len[s] = steps;
+    if (len_keep) len_keep[s] = steps;
 }
 
 // pointer jumping: dist_to_end[s] = len[s] + dist_to_end[nxt[s]]
@@ -255,6 +270,54 @@ __global__ __launch_bounds__(256) void k_ibwt_emit(const uint8_t *__restrict__ b
         put(symbol);
         if (is_splitter(p, S, origin)) break;
         cur = p;
+    }
+    for (uint32_t jj = 0; jj < have; ++jj) out[k - have + jj] = static_cast<uint8_t>(acc >> (8 * jj));
+}
+
+// the text from the walk's records: splitter s owns text[n - dist_to_end[s] .. + len[s]); its first IB_REC bytes are in its record, the
+// rest (walks longer than the record: 2 % of them at S = 64) is walked from resume[s] as k_ibwt_emit does
+__global__ __launch_bounds__(256) void k_ibwt_copy(const uint64_t *__restrict__ psi, uint32_t n, uint32_t origin, uint32_t S, uint32_t nreg,
+                                                    uint32_t nsplit, const uint32_t *__restrict__ dist_to_end, const uint32_t *__restrict__ len,
+                                                    const uint8_t *__restrict__ rec, const uint32_t *__restrict__ resume,
+                                                    uint8_t *__restrict__ out, uint32_t *__restrict__ bad) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsplit) return;
+    if (s != nreg && static_cast<uint64_t>(s) * S >= n) return;
+    const uint32_t d = dist_to_end[s], total = len[s];
+    if (d > n || total > d) { *bad = 1; return; }  // not on the text cycle (corrupt input)
+    uint32_t k = n - d;
+    const bool wide = (reinterpret_cast<uintptr_t>(out) & 7) == 0;
+    uint64_t acc = 0;
+    uint32_t have = 0;
+    auto put = [&](uint8_t b) {
+        if (wide && (have > 0 || (k & 7u) == 0)) {
+            acc |= static_cast<uint64_t>(b) << (8 * have);
+            ++have;
+            ++k;
+            if (have == 8) {
+                *reinterpret_cast<uint64_t *>(out + k - 8) = acc;
+                acc = 0;
+                have = 0;
+            }
+        } else {
+            out[k++] = b;
+        }
+    };
+    const uint64_t *src = reinterpret_cast<const uint64_t *>(rec + static_cast<size_t>(s) * IB_REC);
+    const uint32_t recorded = total < IB_REC ? total : IB_REC;
+    for (uint32_t j = 0; j < recorded; j += 8) {
+        const uint64_t w = src[j >> 3];
+        const uint32_t cnt = recorded - j < 8 ? recorded - j : 8;
+        for (uint32_t b = 0; b < cnt; ++b) put(static_cast<uint8_t>(w >> (8 * b)));
+    }
+    if (total > IB_REC) {
+        uint32_t cur = resume[s], left = total - IB_REC;
+        while (left--) {
+            const uint64_t e = psi[cur];
+            put(static_cast<uint8_t>(e >> 32));
+            cur = static_cast<uint32_t>(e);
+            if (cur == IB_END && left) { *bad = 1; break; }
+        }
     }
     for (uint32_t jj = 0; jj < have; ++jj) out[k - have + jj] = static_cast<uint8_t>(acc >> (8 * jj));
 }
@@ -331,9 +394,15 @@ int bwt_inverse_device(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t ori
     uint32_t *nxt = ctx->ws_alloc<uint32_t>(nsplit), *nxt_alt = ctx->ws_alloc<uint32_t>(nsplit);
     uint32_t *acc = ctx->ws_alloc<uint32_t>(nsplit), *acc_alt = ctx->ws_alloc<uint32_t>(nsplit);
     if (!nxt || !nxt_alt || !acc || !acc_alt) return DK_E_NOMEM;
+    // records of the walk (IB_REC bytes per splitter = 4 n bytes at S = 64): the text is then copied from them instead of walked again
+    const bool record = DK_KNOB("DK_IBWT_RECORD", 1) != 0 && S == 64;
+    uint32_t *len_keep = record ? ctx->ws_alloc<uint32_t>(nsplit) : nullptr;
+    uint32_t *resume = record ? ctx->ws_alloc<uint32_t>(nsplit) : nullptr;
+    uint8_t *rec = record ? ctx->ws_alloc<uint8_t>(static_cast<size_t>(nsplit) * IB_REC) : nullptr;
+    if (record && (!len_keep || !resume || !rec)) return DK_E_NOMEM;
     {
-        LaunchScope ls(ctx, K_IBWT_WALK, 4.0 * n);
-        k_ibwt_walk<<<dim3(div_up(nsplit, 256)), dim3(256), 0, st>>>(psi, static_cast<uint32_t>(n), origin, S, nreg, nsplit, nxt, acc);
+        LaunchScope ls(ctx, K_IBWT_WALK, (record ? 5.0 : 4.0) * n);
+        k_ibwt_walk<<<dim3(div_up(nsplit, 256)), dim3(256), 0, st>>>(psi, static_cast<uint32_t>(n), origin, S, nreg, nsplit, nxt, acc, len_keep, rec, resume);
     }
     DK_HIP(ctx, hipGetLastError());
     // Pointer jumping halves every chain per step: ceil(log2(nsplit)) + 1 steps finish any single path through the splitters.
@@ -357,9 +426,13 @@ int bwt_inverse_device(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t ori
     uint32_t *d_bad = ctx->d_mail + 11;
     DK_HIP(ctx, hipMemsetAsync(d_bad, 0, sizeof(uint32_t), st));
     {
-        LaunchScope ls(ctx, K_IBWT_EMIT, 6.0 * n);
-        k_ibwt_emit<<<dim3(div_up(nsplit, 256)), dim3(256), 0, st>>>(d_bwt, psi, static_cast<uint32_t>(n), origin, S, nreg, nsplit, acc,
-                                                                      d_out, d_bad);
+        LaunchScope ls(ctx, K_IBWT_EMIT, (record ? 2.0 : 6.0) * n);
+        if (record)
+            k_ibwt_copy<<<dim3(div_up(nsplit, 256)), dim3(256), 0, st>>>(psi, static_cast<uint32_t>(n), origin, S, nreg, nsplit, acc, len_keep, rec, resume,
+                                                                          d_out, d_bad);
+        else
+            k_ibwt_emit<<<dim3(div_up(nsplit, 256)), dim3(256), 0, st>>>(d_bwt, psi, static_cast<uint32_t>(n), origin, S, nreg, nsplit, acc,
+                                                                          d_out, d_bad);
     }
     DK_HIP(ctx, hipGetLastError());
     DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 11, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, st));

@@ -56,7 +56,8 @@ __device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ L, size_t
 
 __global__ __launch_bounds__(DC_BLOCK) void k_dc_summary(const uint8_t *__restrict__ L, size_t n, size_t ntiles,
                                                           uint32_t *__restrict__ tile_last, uint32_t *__restrict__ tile_lrun,
-                                                          uint32_t *__restrict__ tile_runs, uint32_t *__restrict__ tile_syms) {
+                                                          uint32_t *__restrict__ tile_runs, uint32_t *__restrict__ tile_syms,
+                                                          uint32_t *__restrict__ tile_set) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[DC_WAVES][DC_PAD + DC_TILE + 16];
     // per symbol: (last position inside the tile + 1) << 13 | run index inside the tile + 1 -- both are at most DC_TILE and grow
     // together, so ONE LDS max per run end keeps the pair
@@ -88,16 +89,23 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_summary(const uint8_t *__restri
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    uint32_t distinct = 0;
+    uint32_t distinct = 0, set4 = 0;
     for (int k = 0; k < 4; ++k) {
         const uint32_t packed = s_last[wave][k * 64 + lane];
         tile_last[tile * 256 + k * 64 + lane] = packed ? static_cast<uint32_t>(base) + (packed >> 13) : 0u;  // position + 1
         tile_lrun[tile * 256 + k * 64 + lane] = packed & 0x1FFFu;
-        distinct += static_cast<uint32_t>(__popcll(__ballot(packed != 0)));
+        uint64_t present = __ballot(packed != 0);
+        while (present && distinct < 4) {  // (wave-uniform) the first four symbols of the tile, in symbol order
+            set4 |= static_cast<uint32_t>(k * 64 + __builtin_ctzll(present)) << (8 * distinct);
+            present &= present - 1;
+            ++distinct;
+        }
+        distinct += static_cast<uint32_t>(__popcll(present));
     }
     if (lane == 0) {
         tile_runs[tile] = runs;
         tile_syms[tile] = distinct;  // distinct symbols of the tile: k_dc_main picks its routes by it
+        tile_set[tile] = set4;       // and, when there are at most four, which
     }
 }
 
@@ -233,6 +241,111 @@ __device__ __forceinline__ uint32_t write_lane(uint32_t value, int sel, uint32_t
     return old;
 }
 
+// Tiles with at most FOUR distinct symbols ({A,C,G,T}; stretches of text made of long runs).  No symbol matching, no dominance count:
+// one ballot per symbol of the tile gives, for every lane, the last lane before it that holds that symbol (a masked find-first-bit-high);
+// with the wave-uniform carries (last occurrence of each of the four before the chunk) that is the last occurrence of every symbol before
+// every lane, and the rank of a run start is the number of the other three whose last occurrence lies behind the run's own previous one.
+// Only a symbol's FIRST run start inside the tile (at most four per tile) has its previous occurrence in front of the tile, where symbols
+// that do not occur in the tile count as well: those lanes add what the 256-entry table of the tile's start says.
+// About 70 vector instructions per chunk instead of 270.
+struct FewOut {
+    uint32_t *dist; uint8_t *sym; uint8_t *rank; uint32_t *run_end; uint32_t *init; uint32_t *final_last; uint32_t *final_lrun;
+};
+__device__ __forceinline__ void dc_tile_few(const uint8_t *s, uint32_t before_tile, size_t n, size_t base, int lane, uint32_t nsym, uint32_t set4,
+                                            const uint2 *pr, uint32_t r, bool last_tile, const FewOut &o) {
+    const uint32_t base32 = static_cast<uint32_t>(base);
+    const uint64_t lt = lanemask_lt(lane);
+    uint32_t symq[4], cpos[4], crun[4], tpos[4];  // wave-uniform: the tile's symbols; their last occurrence (+1) and its run (+1) before the
+                                                   // current chunk; the same at the tile's start
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        symq[q] = (set4 >> (8 * q)) & 0xFFu;
+        const uint2 e = pr[symq[q]];
+        cpos[q] = tpos[q] = static_cast<uint32_t>(q) < nsym ? __builtin_amdgcn_readfirstlane(e.x) : 0u;
+        crun[q] = static_cast<uint32_t>(q) < nsym ? __builtin_amdgcn_readfirstlane(e.y) : 0u;
+    }
+    const uint4 mine = make_uint4(pr[lane].x, pr[64 + lane].x, pr[128 + lane].x, pr[192 + lane].x);  // the table of the tile's start
+    for (int chunk = 0; chunk < DC_TILE / 64; ++chunk) {
+        const int j = chunk * 64 + lane;
+        const size_t p = base + j;
+        const bool valid = p < n;
+        if (__ballot(valid) == 0) break;
+        const uint32_t c = s[j];
+        const uint32_t pc = j ? s[j - 1] : before_tile;
+        const bool start = valid && (p == 0 || c != pc);
+        const uint64_t S = __ballot(start);
+        const uint32_t cb1 = base32 + static_cast<uint32_t>(chunk * 64) + 1u;  // (position of lane 0) + 1
+        uint64_t M[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) M[q] = static_cast<uint32_t>(q) < nsym ? __ballot(valid && c == symq[q]) : 0ull;
+        const uint32_t starts_before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(S >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(S), 0u));
+        const uint32_t run1 = r + starts_before + (start ? 1u : 0u);  // (index of the run holding this lane) + 1
+        if (S != 0) {
+            int kq = 0;  // which of the tile's symbols this lane holds
+#pragma unroll
+            for (int q = 1; q < 4; ++q) kq = (static_cast<uint32_t>(q) < nsym && c == symq[q]) ? q : kq;
+            uint32_t lp1[4];  // last occurrence (+1) of every symbol of the tile before this lane
+            int prevlane = -1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint64_t m = M[q] & lt;
+                const int pl = m ? 63 - __builtin_clzll(m) : -1;
+                lp1[q] = pl >= 0 ? cb1 + static_cast<uint32_t>(pl) : cpos[q];
+                if (q == kq) prevlane = pl;
+            }
+            const uint32_t b1 = kq == 0 ? lp1[0] : kq == 1 ? lp1[1] : kq == 2 ? lp1[2] : lp1[3];
+            uint32_t cnt = 0;  // (0 for a symbol's first occurrence in the block: there is no previous occurrence to count from)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cnt += (b1 != 0 && q != kq && lp1[q] > b1) ? 1u : 0u;
+            // first run start of a symbol inside the tile: its previous occurrence (if any) lies in front of the tile
+            uint64_t slow = __ballot(start && b1 != 0 && b1 <= base32);
+            while (slow) {
+                const int bit = __builtin_ctzll(slow);
+                slow &= slow - 1;
+                const uint32_t sb1 = __builtin_amdgcn_readlane(b1, bit);
+                uint32_t extra = static_cast<uint32_t>(__popcll(__ballot(mine.x > sb1)) + __popcll(__ballot(mine.y > sb1)) +
+                                                       __popcll(__ballot(mine.z > sb1)) + __popcll(__ballot(mine.w > sb1)));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) extra -= tpos[q] > sb1 ? 1u : 0u;  // the tile's own symbols are counted from their occurrences
+                cnt = write_lane(static_cast<uint32_t>(__builtin_amdgcn_readlane(cnt, bit)) + extra, bit, cnt);
+            }
+            const uint32_t prun_in = static_cast<uint32_t>(__shfl(static_cast<int>(run1), prevlane >= 0 ? prevlane : lane, 64));
+            if (start) {
+                const uint32_t i = base32 + static_cast<uint32_t>(j);
+                const uint32_t ridx = r + starts_before;
+                (o.sym + r)[starts_before] = static_cast<uint8_t>(c);
+                if (o.rank) (o.rank + r)[starts_before] = static_cast<uint8_t>(cnt);
+                const uint32_t prun1 = prevlane >= 0 ? prun_in : (kq == 0 ? crun[0] : kq == 1 ? crun[1] : kq == 2 ? crun[2] : crun[3]);
+                if (b1) o.dist[prun1 - 1u] = i - b1 - cnt;  // = i - b - rank - 1
+                else o.init[c] = i;                         // first occurrence in the block
+                if (o.run_end && ridx > 0) o.run_end[ridx - 1] = i - 1;
+            }
+        }
+        // carries: the last lane of every symbol of this chunk (a chunk without a run start continues the open run: same rule)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (M[q]) {  // wave-uniform
+                const int l = 63 - __builtin_clzll(M[q]);
+                cpos[q] = cb1 + static_cast<uint32_t>(l);
+                crun[q] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(run1), l));
+            }
+        }
+        r += static_cast<uint32_t>(__popcll(S));
+    }
+    if (last_tile) {  // publish the final table for the sweep (the last run ends at n-1)
+        if (o.run_end && lane == 0) o.run_end[r - 1] = static_cast<uint32_t>(n - 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint2 e = pr[k * 64 + lane];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (static_cast<uint32_t>(q) < nsym && symq[q] == static_cast<uint32_t>(k * 64 + lane)) e = make_uint2(cpos[q], crun[q]);
+            o.final_last[k * 64 + lane] = e.x;
+            o.final_lrun[k * 64 + lane] = e.y;
+        }
+    }
+}
+
 // One wave per tile.  Per 64-position chunk (lane = position) the ranks are found lane-parallel:
 //   case A  the run's symbol already occurred in this chunk, last at lane w: rank = number of lanes q in (w, lane) that are the
 //           first of their symbol inside that window (prevsame[q] <= w) -- a dominance count on the predecessors (wave_dominance), or
@@ -248,7 +361,7 @@ __device__ __forceinline__ uint32_t write_lane(uint32_t value, int sel, uint32_t
 __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict__ L, size_t n, size_t ntiles,
                                                        const uint32_t *__restrict__ carry_last, const uint32_t *__restrict__ carry_lrun,
                                                        const uint32_t *__restrict__ tile_run_base, const uint32_t *__restrict__ tile_syms,
-                                                       uint32_t *__restrict__ dist,
+                                                       const uint32_t *__restrict__ tile_set, uint32_t *__restrict__ dist,
                                                        uint8_t *__restrict__ sym, uint8_t *__restrict__ rank, uint32_t *__restrict__ run_end,
                                                        uint32_t *__restrict__ init, uint32_t *__restrict__ final_last,
                                                        uint32_t *__restrict__ final_lrun) {
@@ -295,6 +408,12 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
     const uint64_t lt = lanemask_lt(lane), le = lt | (1ull << lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    const uint32_t nsym = __builtin_amdgcn_readfirstlane(tile_syms[tile]);
+    if (nsym <= 4u) {  // wave-uniform: the whole tile takes the four-symbol route
+        const FewOut fo{dist, sym, rank, run_end, init, final_last, final_lrun};
+        dc_tile_few(s, before_tile, n, base, lane, nsym, __builtin_amdgcn_readfirstlane(tile_set[tile]), pr, r, tile == ntiles - 1, fo);
+        return;
+    }
     for (int chunk = 0; chunk < DC_TILE / 64; ++chunk) {
         const int j = chunk * 64 + lane;
         const size_t p = base + j;
@@ -562,14 +681,15 @@ int dc_encode_device(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t init_
     uint32_t *tile_lrun = ctx->ws_alloc<uint32_t>(ntiles * 256);
     uint32_t *tile_runs = ctx->ws_alloc<uint32_t>(ntiles);
     uint32_t *tile_syms = ctx->ws_alloc<uint32_t>(ntiles);
+    uint32_t *tile_set = ctx->ws_alloc<uint32_t>(ntiles);
     uint32_t *chunk_last = ctx->ws_alloc<uint32_t>(nchunks * 256);
     uint32_t *chunk_lrun = ctx->ws_alloc<uint32_t>(nchunks * 256);
     uint32_t *d_init = ctx->ws_alloc<uint32_t>(256);
     uint32_t *d_final = ctx->ws_alloc<uint32_t>(512);
-    if (!tile_last || !tile_lrun || !tile_runs || !tile_syms || !chunk_last || !chunk_lrun || !d_init || !d_final) return DK_E_NOMEM;
+    if (!tile_last || !tile_lrun || !tile_runs || !tile_syms || !tile_set || !chunk_last || !chunk_lrun || !d_init || !d_final) return DK_E_NOMEM;
     {
         LaunchScope ls(ctx, K_DC_SUMMARY, 1.0 * n + 2048.0 * ntiles);
-        k_dc_summary<<<dim3(nblocks), dim3(DC_BLOCK), 0, st>>>(d_bwt, n, ntiles, tile_last, tile_lrun, tile_runs, tile_syms);
+        k_dc_summary<<<dim3(nblocks), dim3(DC_BLOCK), 0, st>>>(d_bwt, n, ntiles, tile_last, tile_lrun, tile_runs, tile_syms, tile_set);
     }
     {
         LaunchScope ls(ctx, K_DC_CARRY, 3.0 * 2048.0 * ntiles);
@@ -581,7 +701,7 @@ int dc_encode_device(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t init_
     }
     {
         LaunchScope ls(ctx, K_DC_MAIN, 1.0 * n + 2048.0 * ntiles);
-        k_dc_main<<<dim3(nblocks), dim3(DC_BLOCK), 0, st>>>(d_bwt, n, ntiles, tile_last, tile_lrun, tile_runs, tile_syms, d_dist, d_sym, d_rank,
+        k_dc_main<<<dim3(nblocks), dim3(DC_BLOCK), 0, st>>>(d_bwt, n, ntiles, tile_last, tile_lrun, tile_runs, tile_syms, tile_set, d_dist, d_sym, d_rank,
                                                             d_run_end, d_init, d_final, d_final + 256);
     }
     {

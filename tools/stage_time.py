@@ -2,6 +2,7 @@
 
     python tools/stage_time.py sa  [N] [text|acgt|random]     suffix sort + BWT (dk_dev_bwt_forward)
     python tools/stage_time.py dc  [N] [text|acgt|random]     distance coding (dk_dev_dc_encode); "text" = the BWT of the text block
+    python tools/stage_time.py ibwt [N] [text|acgt|random]    inverse BWT (dk_dev_bwt_inverse) of the block's BWT
 
 REPS=k repeats each measurement k times (default 4).  DARK_AMD_LIB=path/to/other/libdark_amd.so times another build of the library
 (A/B runs inside one gpurun call; box-to-box variation is a few per cent).  Under `rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU ...`
@@ -43,6 +44,9 @@ def main():
                 t, out = out, t
             dist = torch.empty(n, dtype=torch.int32, device="cuda")
             rank = torch.empty(n, dtype=torch.uint8, device="cuda")
+        if stage == "ibwt":
+            origin = ctx.dev_bwt_forward(t, n, out)
+            back = torch.empty(n, dtype=torch.uint8, device="cuda")
         torch.cuda.synchronize()
         plain, kernels, passes = [], {}, 0
         for prof in (True, False):
@@ -52,6 +56,8 @@ def main():
                 t0 = time.perf_counter()
                 if stage == "dc":
                     ctx.dev_dc_encode(t, n, dist, out, rank)
+                elif stage == "ibwt":
+                    ctx.dev_bwt_inverse(out, n, origin, back)
                 else:
                     ctx.dev_bwt_forward(t, n, out)
                 wall = (time.perf_counter() - t0) * 1e3
@@ -60,12 +66,14 @@ def main():
                 if kern:
                     kernels = kern
                 if not prof:
-                    plain.append(st["ms_dc"] if stage == "dc" else st["ms_sa"] + st["ms_bwt"])
+                    plain.append(st["ms_dc"] if stage == "dc" else st["ms_ibwt"] if stage == "ibwt" else st["ms_sa"] + st["ms_bwt"])
                 passes = st["sort_passes"]
                 print(lib, stage, kind, n, "events" if prof else "plain", "wall %.2f ms  stage %.2f ms  rounds %d" %
-                      (wall, st["ms_dc"] if stage == "dc" else st["ms_sa"] + st["ms_bwt"], st["rounds"]), kern, flush=True)
+                      (wall, st["ms_dc"] if stage == "dc" else st["ms_ibwt"] if stage == "ibwt" else st["ms_sa"] + st["ms_bwt"], st["rounds"]), kern, flush=True)
         print("SUMMARY", lib, stage, kind, n, "median plain %.3f ms" % sorted(plain)[len(plain) // 2], "passes", passes, "rounds", st["rounds"],
               "| per kernel (one profiled step):", " ".join("%s=%.3f" % (k[2:], v) for k, v in sorted(kernels.items(), key=lambda x: -x[1])))
+        if stage == "ibwt":
+            assert torch.equal(back, t), "inverse BWT does not give the block back"
         print("checksum", int(out[: 1 << 22].to(torch.int64).sum()))
 
 
