@@ -71,6 +71,32 @@ def test_five_megabyte_blocks(orc):
     del rng
 
 
+def test_pathological_inputs(orc):
+    """Worst cases of prefix doubling (the reference's SA-IS is linear: README.md:12, src/saca.rs:5-6) at suite size; tools/pathological.py
+    runs them at 1e8 bytes (profiles/r03_pathological.json).  Besides parity: the radix passes per round stay bounded -- round 2 keyed
+    the global sort by the group's OFFSET in the big list (24 bits for two giant groups) instead of its dense index (1 bit): 142 passes
+    on (ab)^2^23 where 83 do."""
+    from dark_amd import datagen
+    half = datagen.wiki_like(1_500_000, 3)
+    a, b = b"a", b"ab"
+    while len(b) < (1 << 21):
+        a, b = b, b + a
+    cases = {"(ab)^2^20": np.frombuffer(b"ab" * (1 << 20), np.uint8), "a^n b": np.concatenate([np.zeros((1 << 21) - 1, np.uint8), np.ones(1, np.uint8)]),
+             "fibonacci word": np.frombuffer(b[:1 << 21], np.uint8), "two identical halves": np.concatenate([half, half]),
+             "period 1000": np.tile(np.random.default_rng(1).integers(0, 256, 1000, dtype=np.uint8), 2500)}
+    with dark_amd.Context(3 << 20) as c:
+        for name, t in cases.items():
+            t = np.ascontiguousarray(t)
+            want = orc.sa_sais(t)
+            assert first_diff(c.suffix_array(t), want) is None, name
+            st = c.stats()
+            assert st["sort_passes"] <= 5 * st["rounds"] + 8, (name, st["sort_passes"], st["rounds"])
+            bwt, origin = c.bwt_forward(t)
+            wb, wo = orc.bwt_forward(t, want)
+            assert origin == wo and first_diff(bwt, wb) is None, name
+            assert first_diff(c.bwt_inverse(bwt, origin), t) is None, name
+
+
 def test_known_answers_saca_rs_411(ctx, vectors):
     # /root/reference/src/saca.rs:409-413 `detailed`, through the GPU path
     for v in vectors["reference"]["saca_rs_411_412"]:

@@ -2,7 +2,7 @@
 # Runs on the GPU box (through gpurun, from the repo root): rocprofv3 kernel-trace statistics and the two PMC passes of the bench
 # command for one workload; everything lands under gpurun_out/prof_<workload>/.  The PMC passes are separate runs with counters only
 # (no trace domains).  bench.py runs WARMUP + STEPS steps with HIP-event pairs and 3 more without: all of them are in the counters.
-# usage: tools/profile_round.sh WORKLOAD [STEPS] [WARMUP]
+# usage: tools/profile_round.sh WORKLOAD [STEPS] [WARMUP]   (results: gpurun_out/prof_<workload>/, to be copied to profiles/rNN_*)
 set -e -o pipefail
 WL=${1:-enwik8_like_1e8}
 STEPS=${2:-2}
