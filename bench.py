@@ -554,10 +554,15 @@ def main():
                     per_step = min(per_step, kern[kk]["bytes"] / k)
                 useful += per_step
             ach_u = min(b_formula, useful) / (fwd_ms * 1e-3) / 1e9
+            fwd_ms_prof = per["ms_sa"] + per["ms_bwt"]  # the timed steps themselves (with the HIP-event pairs of the per-kernel times)
             fwd_roofline = {"B_fwd_formula_bytes": b_formula, "rounds": R, "passes_P": P, "measured_hbm_bytes": round(measured),
                             "t_fwd_ms": round(fwd_ms, 3), "achieved_GBs": round(ach, 1), "frac_of_8TBs": round(ach / HBM_PEAK_GBS, 4),
                             "useful_hbm_bytes": round(useful), "achieved_useful_GBs": round(ach_u, 1),
-                            "frac_of_8TBs_useful": round(ach_u / HBM_PEAK_GBS, 4), "traffic_source": pmc_path}
+                            "frac_of_8TBs_useful": round(ach_u / HBM_PEAK_GBS, 4),
+                            "t_fwd_ms_timed_steps": round(fwd_ms_prof, 3),
+                            "frac_of_8TBs_timed_steps": round(min(b_formula, measured) / (fwd_ms_prof * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "time_source": "t_fwd_ms: three extra steps of this run without event pairs; t_fwd_ms_timed_steps: the timed steps",
+                            "traffic_source": pmc_path + " (HBM bytes: a committed rocprofv3 --pmc profile of this command, not this run)"}
         result = {
             "metric": "bwt_encode_MBps", "value": round(world * n * k / elapsed_max / 1e6, 3), "unit": "MB/s",
             "n_gpus": world, "steps": k, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed_max / k, 3),

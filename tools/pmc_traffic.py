@@ -73,7 +73,7 @@ def main():
     ap.add_argument("write_dir")
     ap.add_argument("--steps", type=int, required=True, help="steps (warm-up + timed) the profiled command ran")
     ap.add_argument("--workload", required=True)
-    ap.add_argument("--round", type=int, default=2)
+    ap.add_argument("--round", type=int, default=3)
     args = ap.parse_args()
     fetch = collect(args.fetch_dir, "FETCH_SIZE")
     write = collect(args.write_dir, "WRITE_SIZE")
