@@ -223,19 +223,24 @@ __global__ __launch_bounds__(256) void k_radix_scan_a(const uint32_t *__restrict
     for (size_t t = t0; t < t1; ++t) s += tile_hist[t * 256 + d];
     chunk_sum[g * 256 + d] = s;
 }
-// phase B (one workgroup of 1024): digit-major exclusive scan of the chunk sums; 4 threads share a digit's column
+// phase B (one workgroup of 1024): digit-major exclusive scan of the chunk sums; 4 threads share a digit's column.  A thread's
+// (at most RS_MAX_CHUNKS / 4) values are loaded in one batch and kept in registers: the kernel is one round trip to memory, not 64
 __global__ __launch_bounds__(1024) void k_radix_scan_b(uint32_t *__restrict__ chunk_sum, size_t nchunks) {
     __shared__ uint32_t s_tmp[16 + 1];
     __shared__ uint32_t s_part[4][256];
+    constexpr int QMAX = RS_MAX_CHUNKS / 4;
     const int d = threadIdx.x & 255, part = threadIdx.x >> 8;
-    const size_t q = (nchunks + 3) / 4;
-    const size_t g0 = part * q, g1 = g0 + q < nchunks ? g0 + q : nchunks;
+    const size_t q = (nchunks + 3) / 4;  // <= QMAX
+    const size_t g0 = part * q;
+    uint32_t v[QMAX];
+#pragma unroll
+    for (int k = 0; k < QMAX; ++k) v[k] = (static_cast<size_t>(k) < q && g0 + k < nchunks) ? chunk_sum[(g0 + k) * 256 + d] : 0u;
     uint32_t run = 0;
-#pragma unroll 8
-    for (size_t g = g0; g < g1; ++g) {
-        const uint32_t v = chunk_sum[g * 256 + d];
-        chunk_sum[g * 256 + d] = run;
-        run += v;
+#pragma unroll
+    for (int k = 0; k < QMAX; ++k) {
+        const uint32_t x = v[k];
+        v[k] = run;
+        run += x;
     }
     s_part[part][d] = run;
     __syncthreads();
@@ -251,8 +256,9 @@ __global__ __launch_bounds__(1024) void k_radix_scan_b(uint32_t *__restrict__ ch
     if (part == 0) s_part[0][d] = base;
     __syncthreads();
     const uint32_t off = s_part[0][d] + before;
-#pragma unroll 8
-    for (size_t g = g0; g < g1; ++g) chunk_sum[g * 256 + d] += off;
+#pragma unroll
+    for (int k = 0; k < QMAX; ++k)
+        if (static_cast<size_t>(k) < q && g0 + k < nchunks) chunk_sum[(g0 + k) * 256 + d] = v[k] + off;
 }
 // all three phases in one workgroup, for sorts of few tiles (the big-group lists: a launch costs more than this loop)
 __global__ __launch_bounds__(256) void k_radix_scan_small(uint32_t *__restrict__ tile_hist, size_t ntiles) {
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(256) void k_radix_scan_small(uint32_t *__restrict__
     for (size_t t = 0; t < ntiles; ++t) tile_hist[t * 256 + d] += base;
 }
 
-// phase C: tile counts -> exclusive global offsets
+// phase C: tile counts -> exclusive global offsets (eight rows loaded before any is rewritten: the loads are in flight together)
 __global__ __launch_bounds__(256) void k_radix_scan_c(uint32_t *__restrict__ tile_hist, size_t ntiles, size_t tiles_per_chunk,
                                                        const uint32_t *__restrict__ chunk_sum) {
     const size_t g = blockIdx.x;
@@ -278,10 +284,15 @@ __global__ __launch_bounds__(256) void k_radix_scan_c(uint32_t *__restrict__ til
     const size_t t0 = g * tiles_per_chunk;
     const size_t t1 = t0 + tiles_per_chunk < ntiles ? t0 + tiles_per_chunk : ntiles;
     uint32_t run = chunk_sum[g * 256 + d];
-    for (size_t t = t0; t < t1; ++t) {
-        const uint32_t v = tile_hist[t * 256 + d];
-        tile_hist[t * 256 + d] = run;
-        run += v;
+    for (size_t t = t0; t < t1; t += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = t + k < t1 ? tile_hist[(t + k) * 256 + d] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (t + k < t1) tile_hist[(t + k) * 256 + d] = run;
+            run += v[k];
+        }
     }
 }
 
