@@ -223,24 +223,25 @@ __global__ __launch_bounds__(256) void k_radix_scan_a(const uint32_t *__restrict
     for (size_t t = t0; t < t1; ++t) s += tile_hist[t * 256 + d];
     chunk_sum[g * 256 + d] = s;
 }
-// phase B (one workgroup of 1024): digit-major exclusive scan of the chunk sums; 4 threads share a digit's column.  A thread's
-// (at most RS_MAX_CHUNKS / 4) values are loaded in one batch and kept in registers: the kernel is one round trip to memory, not 64
+// phase B (one workgroup of 1024): digit-major exclusive scan of the chunk sums; 4 threads share a digit's column.  Eight rows are
+// loaded before any is rewritten, so that the loads are in flight together.  (All 64 rows of a thread in registers at once was slower:
+// 39 against 16 us -- the guarded 64-entry array went to scratch.)
 __global__ __launch_bounds__(1024) void k_radix_scan_b(uint32_t *__restrict__ chunk_sum, size_t nchunks) {
     __shared__ uint32_t s_tmp[16 + 1];
     __shared__ uint32_t s_part[4][256];
-    constexpr int QMAX = RS_MAX_CHUNKS / 4;
     const int d = threadIdx.x & 255, part = threadIdx.x >> 8;
-    const size_t q = (nchunks + 3) / 4;  // <= QMAX
-    const size_t g0 = part * q;
-    uint32_t v[QMAX];
-#pragma unroll
-    for (int k = 0; k < QMAX; ++k) v[k] = (static_cast<size_t>(k) < q && g0 + k < nchunks) ? chunk_sum[(g0 + k) * 256 + d] : 0u;
+    const size_t q = (nchunks + 3) / 4;
+    const size_t g0 = part * q, g1 = g0 + q < nchunks ? g0 + q : nchunks;
     uint32_t run = 0;
+    for (size_t g = g0; g < g1; g += 8) {
+        uint32_t v[8];
 #pragma unroll
-    for (int k = 0; k < QMAX; ++k) {
-        const uint32_t x = v[k];
-        v[k] = run;
-        run += x;
+        for (int k = 0; k < 8; ++k) v[k] = g + k < g1 ? chunk_sum[(g + k) * 256 + d] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (g + k < g1) chunk_sum[(g + k) * 256 + d] = run;
+            run += v[k];
+        }
     }
     s_part[part][d] = run;
     __syncthreads();
@@ -256,9 +257,14 @@ __global__ __launch_bounds__(1024) void k_radix_scan_b(uint32_t *__restrict__ ch
     if (part == 0) s_part[0][d] = base;
     __syncthreads();
     const uint32_t off = s_part[0][d] + before;
+    for (size_t g = g0; g < g1; g += 8) {
+        uint32_t v[8];
 #pragma unroll
-    for (int k = 0; k < QMAX; ++k)
-        if (static_cast<size_t>(k) < q && g0 + k < nchunks) chunk_sum[(g0 + k) * 256 + d] = v[k] + off;
+        for (int k = 0; k < 8; ++k) v[k] = g + k < g1 ? chunk_sum[(g + k) * 256 + d] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (g + k < g1) chunk_sum[(g + k) * 256 + d] = v[k] + off;
+    }
 }
 // all three phases in one workgroup, for sorts of few tiles (the big-group lists: a launch costs more than this loop)
 __global__ __launch_bounds__(256) void k_radix_scan_small(uint32_t *__restrict__ tile_hist, size_t ntiles) {
@@ -329,6 +335,8 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))
     const size_t tile_base = static_cast<size_t>(tile) * RS_TILE;
     const size_t left = n - tile_base;
     const uint32_t valid = left < static_cast<size_t>(RS_TILE) ? static_cast<uint32_t>(left) : RS_TILE;
+    // the tile's global digit offsets are needed after the ranking only: asked for here, their latency hides behind it
+    const uint32_t goff_early = tid < 256 ? tile_offs[static_cast<size_t>(tile) * 256 + tid] : 0u;
 
     if (TEXT) {  // keys of the tile, in position order
         text_tile_keys(tk, tile_base, s_code, reinterpret_cast<uint8_t *>(s_tab), [&](int o, uint64_t key) { s_keys[o] = key; });
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))
                 s_cnt[w][d] = run;
                 run += c;
             }
-            goff = tile_offs[static_cast<size_t>(tile) * 256 + d];
+            goff = goff_early;
         }
         const uint32_t start = block_excl_sum<RS_WAVES>(run, s_tmp, nullptr);
         if (owner) {
@@ -687,7 +695,9 @@ __global__ __launch_bounds__(ISP_BLOCK) void k_isa_split(const uint32_t *__restr
         }
     }
     __syncthreads();
-    if (tid < 64) {  // one wave: exclusive scan of the 64 counts, and the tile's place in every bin (one global atomic per bin in use)
+    if (tid < 64) {  // one wave: exclusive scan of the 64 counts, and the tile's place in every bin (one global atomic per bin in use).
+        // (Asking for the place here and using it only after the staging below, to hide the atomic's round trip, was slower: 1.08
+        // against 0.95 ms for the two passes at n = 1e8.)
         const uint32_t c = s_cnt[tid];
         const uint32_t incl = wave_incl_sum(c, tid);
         s_start[tid] = incl - c;
