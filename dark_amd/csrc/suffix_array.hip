@@ -6,10 +6,12 @@
 //   2. k_prefix_probe    (large blocks) does a sample of suffixes separate on a short prefix already?  -> symbols the initial sort covers
 //   3. sort_pairs        (key, i) by key, key = the first s symbols of suffix i packed big-endian (+ the code of the symbol in FRONT of
 //                        the suffix in the low byte when the caller wants L: BwtCarry); the first pass builds the keys from the text
-//   4. rerank            heads where the key changes; singletons are final (written to SA, and L), the rest are compacted into the ACTIVE
-//                        list (idx, slot position, group id, symbol in front)
+//                        -- and its last pass leaves every suffix at its slot of SA, its symbol in L
+//   4. rerank            heads where the key changes (one flag byte per slot); singletons are final where they stand, the rest are
+//                        compacted into the ACTIVE list (idx, slot position, group id, symbol in front)
 //   5a. text rounds      every group sorted inside its slot range by the next 8 bytes of the text (k_round_local<true>); no ranks needed
-//   5b. rank array       built once, for what survived: rank[SA[p]] = p by a bucketed scatter, active suffixes get their head's position
+//   5b. rank array       built once, for what survived: rank[SA[p]] = p -- the inverse permutation through LDS windows (radix_sort.hip);
+//                        active suffixes get their head's position
 //   5c. doubling rounds  secondary key rank[i+h]+h (n-1-i past the end: shorter is smaller); general rounds (k_round_local<false>, big
 //                        groups through the global sort, rerank) while groups of more than 256 members exist, then in-place rounds
 //                        (k_plateau_sort / k_plateau_ranks: no compaction, no scan, live count read back one round late)
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void k_prefix_probe(const uint8_t *__restrict_
 
 // ---- rank array for the doubling rounds when the initial sort did not produce it (short-prefix path) ------------------------------
 // Every suffix that is final sits in SA; put the active ones at their (provisional) places too, store rank[SA[p]] = p for all p
-// with the bucketed scatter, then give the active ones the position of their group's head.
+// (inverse permutation: radix_sort.hip), then give the active ones the position of their group's head.
 __global__ __launch_bounds__(256) void k_place_active(const uint32_t *__restrict__ act_idx, const uint32_t *__restrict__ act_pos, size_t count,
                                                       uint32_t *__restrict__ sa) {
     const size_t a = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -477,7 +479,11 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
 // cost ONE extra bit instead of 24, i.e. three radix passes less per round.  mail[3] = number of slots in groups of more than
 // PL_MAX members (those keep the sort in general rounds; zero = the in-place rounds can take over).
 constexpr int LS_MAX = 1024;  // general rounds: groups up to this size are sorted inside a workgroup's LDS
-constexpr int PL_MAX = 256;   // in-place (plateau) rounds need every group to have at most this many members (9-bit offsets)
+constexpr int PL_BITS = 8;
+constexpr int PL_MAX = 1 << PL_BITS;  // in-place (plateau) rounds need every group to have at most this many members (PL_BITS-bit offsets and
+                                      // sizes in the slot's meta word).  2048 was measured in round 3: the 1e8 text block then skips its one
+                                      // general round (a group of 1336 and 23 076 slots in groups above 256 are all that keeps it), but the
+                                      // in-place rounds start one round earlier on 9.9 instead of 9.2 M slots: 11.63 against 11.55-11.66 ms
 constexpr int BG_IPT = 16;
 constexpr int BG_TILE = 256 * BG_IPT;
 
@@ -666,19 +672,22 @@ __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__rest
             s_r2[LS_MAX + k * LS_BLOCK + tid] = my_r2[k];
         }
     }
-    // halo: up to LS_MAX slots before the tile and after it -- but only those that belong to the group of the tile's first / last slot
-    // (nothing else in the halo is ever looked at), so a halo slot costs its gather only when a group really straddles the tile edge
+    // halo: the slots before / after the tile that belong to the group of the tile's first / last slot (nothing else in the halo is ever
+    // looked at, and a group above LS_MAX goes through the big list: no halo).  Their number follows from the group's extent, so a halo
+    // slot costs its gather only when a group really straddles the tile edge -- and nothing at all otherwise.
     {
         const size_t last = (b0 + LS_TILE <= count ? b0 + LS_TILE : count) - 1;
         const uint32_t g_first = act_gid[b0], g_last = act_gid[last];
-        for (int t = tid; t < 2 * LS_MAX; t += LS_BLOCK) {
-            const bool left = t < LS_MAX;
-            const size_t off = left ? static_cast<size_t>(t) : static_cast<size_t>(LS_TILE) + LS_MAX + (t - LS_MAX);
-            // slot index = b0 - LS_MAX + off; guard both ends of the list
-            if (b0 + off >= static_cast<size_t>(LS_MAX) && b0 + off - LS_MAX < count) {
-                const size_t a = b0 + off - LS_MAX;
-                if (act_gid[a] == (left ? g_first : g_last)) s_r2[off] = second(act_idx[a]);
-            }
+        const uint32_t fs = gstart[g_first], fe = gstart[g_first + 1], ls = gstart[g_last], le = gstart[g_last + 1];
+        const uint32_t need_left = fe - fs <= static_cast<uint32_t>(LS_MAX) ? static_cast<uint32_t>(b0) - fs : 0u;        // slots fs .. b0 - 1
+        const uint32_t need_right = le - ls <= static_cast<uint32_t>(LS_MAX) ? le - static_cast<uint32_t>(last) - 1u : 0u;  // slots last + 1 .. le - 1
+        for (uint32_t t = tid; t < need_left; t += LS_BLOCK) {
+            const size_t a = b0 - 1 - t;
+            s_r2[LS_MAX - 1 - t] = second(act_idx[a]);
+        }
+        for (uint32_t t = tid; t < need_right; t += LS_BLOCK) {
+            const size_t a = last + 1 + t;
+            s_r2[LS_MAX + (last + 1 - b0) + t] = second(act_idx[a]);
         }
     }
     __syncthreads();
@@ -730,7 +739,7 @@ __global__ __launch_bounds__(256) void k_big_back(const uint64_t *__restrict__ b
 // Once a round ends without a big group there will never be one again (groups only split), and what is left are typically the
 // suffixes inside long repeats: the list shrinks slowly for log2(repeat length) rounds.  These rounds run on an IN-PLACE list:
 //   idx[a]   suffix in slot a; bit 31 set = the slot is dead (its suffix is final)
-//   meta[a]  offset of the slot inside its group (9 bits) | (group size - 1) << 9 | PL_MOVED
+//   meta[a]  offset of the slot inside its group (PL_BITS bits) | (group size - 1) << PL_BITS | PL_MOVED
 //   pos[a]   SA position of slot a (never changes: members move only inside their group's slot range)
 // One kernel per round sorts every group inside LDS by the rank of the suffix h further on and writes each member to its place
 // (ping-pong idx / meta / sym): its new group is the run of members with the same secondary rank.  No compaction, no global scan,
@@ -738,7 +747,7 @@ __global__ __launch_bounds__(256) void k_big_back(const uint64_t *__restrict__ b
 // them inside the first would let another workgroup see the new rank of one suffix and the old rank of its group mate -- an order
 // that may contradict both the h-order and the 2h-order.
 constexpr uint32_t PL_DEAD = 0xFFFFFFFFu, PL_DEAD_BIT = 0x80000000u;
-constexpr uint32_t PL_MOVED = 1u << 18, PL_OFF_MASK = 511u;  // the slot's group got a new head this round: its members' ranks change
+constexpr uint32_t PL_MOVED = 1u << (2 * PL_BITS), PL_OFF_MASK = (1u << PL_BITS) - 1u;  // the slot's group got a new head this round: its members' ranks change
 
 __global__ __launch_bounds__(256) void k_to_inplace(const uint32_t *__restrict__ gid, const uint32_t *__restrict__ gstart, size_t count,
                                                      uint32_t *__restrict__ meta) {
@@ -746,7 +755,7 @@ __global__ __launch_bounds__(256) void k_to_inplace(const uint32_t *__restrict__
     if (a >= count) return;
     const uint32_t g = gid[a];
     const uint32_t gs = gstart[g], ge = gstart[g + 1];
-    meta[a] = (static_cast<uint32_t>(a) - gs) | ((ge - gs - 1u) << 9);
+    meta[a] = (static_cast<uint32_t>(a) - gs) | ((ge - gs - 1u) << PL_BITS);
 }
 
 __global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__restrict__ idx_in, const uint32_t *__restrict__ meta_in,
@@ -778,15 +787,14 @@ __global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__res
         const uint32_t m_first = (idx_in[b0] & PL_DEAD_BIT) ? 0u : meta_in[b0];
         const uint32_t m_last = (idx_in[last] & PL_DEAD_BIT) ? 0u : meta_in[last];
         const uint32_t need_left = m_first & PL_OFF_MASK;
-        const uint32_t need_right = (idx_in[last] & PL_DEAD_BIT) ? 0u : ((m_last >> 9) & PL_OFF_MASK) - (m_last & PL_OFF_MASK);
-        for (int t = tid; t < 2 * PL_MAX; t += LS_BLOCK) {
-            const bool left = t < PL_MAX;
-            const size_t off = left ? static_cast<size_t>(t) : static_cast<size_t>(LS_TILE) + PL_MAX + (t - PL_MAX);
-            const bool wanted = left ? static_cast<uint32_t>(PL_MAX - t) <= need_left : static_cast<uint32_t>(t - PL_MAX) < need_right;
-            if (wanted && b0 + off >= static_cast<size_t>(PL_MAX) && b0 + off - PL_MAX < slots) {
-                const uint32_t v = idx_in[b0 + off - PL_MAX];
-                s_r2[off] = (v & PL_DEAD_BIT) ? 0u : rank2_of(rank, v, n, h);
-            }
+        const uint32_t need_right = (idx_in[last] & PL_DEAD_BIT) ? 0u : ((m_last >> PL_BITS) & PL_OFF_MASK) - (m_last & PL_OFF_MASK);
+        for (uint32_t t = tid; t < need_left; t += LS_BLOCK) {  // slots b0 - need_left .. b0 - 1 (inside the list: the group starts there)
+            const uint32_t v = idx_in[b0 - 1 - t];
+            s_r2[PL_MAX - 1 - t] = (v & PL_DEAD_BIT) ? 0u : rank2_of(rank, v, n, h);
+        }
+        for (uint32_t t = tid; t < need_right; t += LS_BLOCK) {  // slots last + 1 .. last + need_right
+            const uint32_t v = idx_in[last + 1 + t];
+            s_r2[PL_MAX + (last + 1 - b0) + t] = (v & PL_DEAD_BIT) ? 0u : rank2_of(rank, v, n, h);
         }
     }
     __syncthreads();
@@ -797,7 +805,7 @@ __global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__res
         if (a >= slots) continue;
         if (my_idx[k] & PL_DEAD_BIT) { idx_out[a] = PL_DEAD; continue; }  // a dead slot is never inside a live group's range
         const uint32_t m = meta_in[a];
-        const uint32_t gs = static_cast<uint32_t>(a) - (m & PL_OFF_MASK), ge = gs + ((m >> 9) & PL_OFF_MASK) + 1u;
+        const uint32_t gs = static_cast<uint32_t>(a) - (m & PL_OFF_MASK), ge = gs + ((m >> PL_BITS) & PL_OFF_MASK) + 1u;
         const uint32_t mine = my_r2[k];
         const uint32_t base = static_cast<uint32_t>(PL_MAX) - static_cast<uint32_t>(b0);  // LDS index of slot b = b + base (mod 2^32)
         uint32_t less = 0, eq_before = 0, eq = 0;
@@ -809,7 +817,7 @@ __global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__res
         }
         const uint32_t dest = gs + less + eq_before;
         const uint32_t moved = less ? PL_MOVED : 0u;  // new head slot gs + less: the rank becomes pos[gs + less]
-        meta_out[dest] = eq_before | ((eq - 1u) << 9) | moved;
+        meta_out[dest] = eq_before | ((eq - 1u) << PL_BITS) | moved;
         if (eq == 1) {  // alone in its new group: final
             const uint32_t p = pos[dest];
             sa[p] = my_idx[k];
