@@ -58,18 +58,36 @@ constexpr int IB_SPT = 16;                    // symbols per thread
 constexpr int IB_TILE = IB_BLOCK * IB_SPT;    // 4096 symbols per workgroup
 constexpr int IB_MAX_CHUNKS = 256;
 
+// 16 private copies of the histogram (copy = lane mod 16): the BWT is made of runs, and LDS atomics of one wave instruction that hit the
+// same counter are serialised (one copy: 0.25 ms per 1e8 bytes; the radix sort's digit-plane histogram has the same shape)
 __global__ __launch_bounds__(IB_BLOCK) void k_ibwt_hist(const uint8_t *__restrict__ bwt, size_t n, uint32_t *__restrict__ tile_hist) {
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+    __shared__ uint32_t h[16][256];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 16 * 256; i += IB_BLOCK) (&h[0][0])[i] = 0;
     __syncthreads();
+    uint32_t *mine = h[tid & 15];
     const size_t base = static_cast<size_t>(blockIdx.x) * IB_TILE;
+    static_assert(IB_TILE == IB_BLOCK * 16, "one 16-byte load per thread");
+    if (base + IB_TILE <= n && (reinterpret_cast<uintptr_t>(bwt) & 15) == 0) {
+        const uint4 v = reinterpret_cast<const uint4 *>(bwt + base)[tid];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int k = 0; k < IB_SPT; ++k) {
-        const size_t i = base + static_cast<size_t>(k) * IB_BLOCK + threadIdx.x;
-        if (i < n) atomicAdd(&h[bwt[i]], 1u);
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) atomicAdd(&mine[(w[k] >> (8 * b)) & 0xFFu], 1u);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < IB_SPT; ++k) {
+            const size_t i = base + static_cast<size_t>(k) * IB_BLOCK + tid;
+            if (i < n) atomicAdd(&mine[bwt[i]], 1u);
+        }
     }
     __syncthreads();
-    tile_hist[static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x] = h[threadIdx.x];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) sum += h[c][tid];
+    tile_hist[static_cast<size_t>(blockIdx.x) * 256 + tid] = sum;
 }
 // digit-major exclusive scan of tile_hist, same three phases as the radix sort; class_start[256] also exported
 __global__ __launch_bounds__(256) void k_ibwt_scan_a(const uint32_t *__restrict__ tile_hist, size_t ntiles, size_t tpc,

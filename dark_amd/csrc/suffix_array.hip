@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_prefix_probe(const uint8_t *__restrict_
     }
 }
 
-// ---- rank array for the doubling rounds when the initial sort did not produce it (short-prefix path) ------------------------------
+// ---- rank array for the doubling rounds, built once for whatever the text rounds leave -------------------------------------------
 // Every suffix that is final sits in SA; put the active ones at their (provisional) places too, store rank[SA[p]] = p for all p
 // (inverse permutation: radix_sort.hip), then give the active ones the position of their group's head.
 __global__ __launch_bounds__(256) void k_place_active(const uint32_t *__restrict__ act_idx, const uint32_t *__restrict__ act_pos, size_t count,

@@ -401,8 +401,8 @@ def test_group_size_classes(ctx, orc):
     check_all_stages(ctx, orc, np.ascontiguousarray(t), models=("dark",))
 
 
-def test_bucketed_scatter_threshold(ctx, orc):
-    # the first rerank switches to the bucketed rank scatter at n = 2^22
+def test_sizes_around_2p22(ctx, orc):
+    # 2^22 bytes: the prefix probe starts to run, and the inverse permutation's windows grow beyond 1024 words (two levels, wbits 10 -> 11)
     rng = np.random.default_rng(61)
     base = text_like(rng, (1 << 22) + 8, vocab=30000)
     for n in ((1 << 22) - 1, 1 << 22, (1 << 22) + 1):
