@@ -7,7 +7,7 @@ namespace dk {
 
 const char *kernel_slot_name(int slot) {
     // a slot is named after the kernel it brackets, exactly as rocprofv3 prints it; a slot that brackets several kernels launched
-    // back to back carries their common prefix (k_radix_scan = k_radix_scan_a + _b + _c, see the enum)
+    // back to back carries their common prefix (k_rerank_scan = k_rerank_scan + _a + _c, see the enum)
     static const char *names[K_SLOT_COUNT] = {
         "k_sym_hist",     "k_radix_hist",  "k_radix_scan",    "k_radix_scatter", "k_rerank_reduce", "k_rerank_scan",
         "k_rerank_apply", "k_round_local",  "k_bwt_gather",  "k_dc_summary",    "k_dc_carry",      "k_dc_main",       "k_dc_sweep",

@@ -19,7 +19,7 @@ namespace dk {
 enum KernelSlot : int {
     K_SYM_HIST = 0,
     K_RADIX_HIST,
-    K_RADIX_SCAN,      // k_radix_scan_a + _b + _c (one bracket)
+    K_RADIX_SCAN,      // k_radix_scan
     K_RADIX_SCATTER,
     K_RERANK_REDUCE,
     K_RERANK_SCAN,
@@ -43,7 +43,7 @@ enum KernelSlot : int {
     K_PLATEAU_SORT,
     K_PLATEAU_RANKS,   // k_plateau_ranks, k_to_inplace, k_plateau_count/_scan/_compact
     K_RADIX_SORT_SMALL,
-    K_RADIX_HIST_TEXT,     // k_radix_hist<false, true>: first pass, digits straight from the text (1 B per key)
+    K_RADIX_HIST_TEXT,     // k_radix_hist<HS_TEXT>: first pass, digits straight from the text (1 B per key)
     K_RADIX_SCATTER_TEXT,  // k_radix_scatter<false, true>: first pass, keys built from the text (13 B per pair)
     K_ISA_PARTITION,       // k_isa_init + k_isa_split<true> + k_isa_split<false> (inverse permutation through LDS windows)
     K_ISA_ASSEMBLE,        // k_isa_assemble

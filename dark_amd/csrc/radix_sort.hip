@@ -2,15 +2,17 @@
 // It takes the place of all the sorting work inside saca() (src/saca.rs:270-340): bucket placement, the induced
 // sorts and the naming pass become "sort by packed prefix, then by the symbols / ranks further on".
 //
-// Per pass, three phases:
-//   k_radix_hist        per-tile 256-bin digit histograms (LDS atomics over 16 private copies: text digits are skewed); from the second
-//                       pass on they are counted from the one-byte DIGIT PLANE the previous pass's scatter wrote beside the pairs
-//                       (k_radix_hist_plane: n bytes read instead of 8 n)
-//   k_radix_scan_a/b/c  digit-major exclusive scan of the tile histograms -> global offset of every (tile, digit)
+// Per pass, three launches:
+//   k_radix_hist        one workgroup per CHUNK of consecutive tiles keeps a cumulative 256-bin histogram in LDS (16 copies per digit)
+//                       and leaves, per tile, the count of every digit in the chunk's earlier tiles; from the second pass on the
+//                       digits come from the one-byte DIGIT PLANE the previous pass's scatter wrote beside the pairs (n bytes read
+//                       instead of 8 n), in the first pass of the suffix sort straight from the text
+//   k_radix_scan        chunk totals -> pairs with a smaller digit + pairs with the same digit in earlier chunks (one wave per digit)
 //   k_radix_scatter     a tile ranks its pairs stably with wave64 ballots (match-any over the 8 digit bits), reorders them in LDS so
 //                       that equal digits are contiguous, then writes runs to HBM.  XCD-aware tile order: every XCD takes one
 //                       contiguous range of tiles, so the short output runs of neighbouring tiles meet in the same L2.
-// Algorithmic bytes per pass: scatter 12 B/pair read + 12 (+1: digit plane) B/pair written; histogram 8 B/key, 1 B with the plane.
+// Algorithmic bytes per pass: scatter 12 B/pair read + 12 (+1: digit plane) B/pair written; histogram 8 B/key, 1 B with the plane,
+// + 1 KiB per tile (the table is written once by the histogram and read once by the scatter).
 // (Two single-kernel-per-pass variants with decoupled look-back -- global ticket order, and per-XCD chunks with the next pass's
 // histograms accumulated while scattering -- were built and measured in round 1: 2.2 TB/s and 1.04 ms per pass of 1e8 pairs against
 // 0.81 ms for these three phases.  They lost and were removed; DESIGN.md section 4.1 keeps the numbers.)
@@ -33,8 +35,8 @@ constexpr int RS_BLOCK = DK_RS_BLOCK;        // threads per workgroup.  512 (819
 constexpr int RS_WAVES = RS_BLOCK / 64;
 constexpr int RS_KPT = 16;                   // pairs per thread
 constexpr int RS_TILE = RS_BLOCK * RS_KPT;   // 4096 pairs per workgroup
+
 constexpr int RS_TEXT_AHEAD = 64 + 16;       // TextKeys: codes staged beyond the tile (spk <= 64)
-constexpr int RS_MAX_CHUNKS = 256;
 
 __device__ __forceinline__ uint32_t digit_of(uint64_t k, int shift) { return static_cast<uint32_t>(k >> shift) & 0xFFu; }
 
@@ -51,28 +53,56 @@ __device__ __forceinline__ uint64_t load_key(const uint64_t *__restrict__ keys, 
 // (shifted up one byte with the code of T[i-1] below when with_prev), its value is i.  The first pass's histogram and scatter
 // kernels build the keys of their tile in LDS from n bytes of text instead of reading 12 n bytes of (key, index) pairs that a
 // separate kernel would have had to write first.
-// the codes of T[b0 .. b0 + RS_TILE + RS_TEXT_AHEAD) into s_c (zero past the end of the text), the code of the symbol in front of the
-// tile into s_c[RS_TILE + RS_TEXT_AHEAD]; ends with a barrier
-__device__ __forceinline__ void text_stage_codes(const TextKeys &tk, size_t b0, uint8_t *s_code, uint8_t *s_c) {
+// Staging of a tile: the codes of T[b0 .. b0 + RS_TILE + RS_TEXT_AHEAD) into s_c (zero past the end of the text), the code of the symbol in
+// front of the tile into s_c[RS_TILE + RS_TEXT_AHEAD].  In two halves, so that a kernel that walks several tiles can ask for the bytes of
+// the next one before it works on the current one: text_fetch (global memory -> registers; only when the whole range lies inside an
+// aligned text) and text_stage (registers -> code table -> s_c; ends with a barrier; s_code must be loaded and visible).
+constexpr int RS_TEXT_TAIL = (RS_TEXT_AHEAD + 15) / 16;  // threads that fetch a second slice (the codes beyond the tile)
+static_assert(RS_TEXT_TAIL < 64 && RS_BLOCK > 64, "thread 64 fetches the byte in front of the tile");
+struct TextRaw { uint4 a, b; uint32_t before; };
+__device__ __forceinline__ bool text_fast(const TextKeys &tk, size_t b0) {
+    return (reinterpret_cast<uintptr_t>(tk.t) & 15) == 0 && b0 + RS_TILE + RS_TEXT_TAIL * 16 <= tk.n;
+}
+__device__ __forceinline__ void text_fetch(const TextKeys &tk, size_t b0, TextRaw &r) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < 256; i += RS_BLOCK) s_code[i] = tk.code[i];
-    __syncthreads();
-    if (tid == 0) s_c[RS_TILE + RS_TEXT_AHEAD] = s_code[tk.t[b0 ? b0 - 1 : tk.n - 1]];  // code of the symbol in front of the tile
-    const bool aligned = (reinterpret_cast<uintptr_t>(tk.t) & 15) == 0;
-    for (int o = tid * 16; o < RS_TILE + RS_TEXT_AHEAD; o += RS_BLOCK * 16) {
-        const size_t p = b0 + o;
-        uint8_t raw[16];
-        if (aligned && p + 16 <= tk.n) {
-            *reinterpret_cast<uint4 *>(raw) = *reinterpret_cast<const uint4 *>(tk.t + p);
+    if (!text_fast(tk, b0)) return;
+    r.a = *reinterpret_cast<const uint4 *>(tk.t + b0 + tid * 16);
+    if (tid < RS_TEXT_TAIL) r.b = *reinterpret_cast<const uint4 *>(tk.t + b0 + RS_TILE + tid * 16);
+    if (tid == 64) r.before = tk.t[b0 ? b0 - 1 : tk.n - 1];
+}
+__device__ __forceinline__ uint4 text_codes16(uint4 raw, const uint8_t *s_code) {
+    uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-            for (int b = 0; b < 16; ++b) raw[b] = s_code[raw[b]];
-        } else {
+    for (int k = 0; k < 4; ++k)
+        w[k] = s_code[w[k] & 0xFFu] | (static_cast<uint32_t>(s_code[(w[k] >> 8) & 0xFFu]) << 8) | (static_cast<uint32_t>(s_code[(w[k] >> 16) & 0xFFu]) << 16) |
+               (static_cast<uint32_t>(s_code[w[k] >> 24]) << 24);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ void text_stage(const TextKeys &tk, size_t b0, const TextRaw &r, const uint8_t *s_code, uint8_t *s_c) {
+    const int tid = threadIdx.x;
+    if (text_fast(tk, b0)) {
+        *reinterpret_cast<uint4 *>(s_c + tid * 16) = text_codes16(r.a, s_code);
+        if (tid < RS_TEXT_TAIL) *reinterpret_cast<uint4 *>(s_c + RS_TILE + tid * 16) = text_codes16(r.b, s_code);
+        if (tid == 64) s_c[RS_TILE + RS_TEXT_AHEAD] = s_code[r.before & 0xFFu];
+    } else {
+        if (tid == 0) s_c[RS_TILE + RS_TEXT_AHEAD] = s_code[tk.t[b0 ? b0 - 1 : tk.n - 1]];  // code of the symbol in front of the tile
+        for (int o = tid * 16; o < RS_TILE + RS_TEXT_AHEAD; o += RS_BLOCK * 16) {
+            const size_t p = b0 + o;
+            uint8_t raw[16];
 #pragma unroll
             for (int b = 0; b < 16; ++b) raw[b] = (p + b < tk.n) ? s_code[tk.t[p + b]] : 0;  // zero padding past the end of the text
+            *reinterpret_cast<uint4 *>(s_c + o) = *reinterpret_cast<const uint4 *>(raw);
         }
-        *reinterpret_cast<uint4 *>(s_c + o) = *reinterpret_cast<const uint4 *>(raw);
     }
     __syncthreads();
+}
+// both halves and the code table, for a kernel that sees one tile
+__device__ __forceinline__ void text_stage_codes(const TextKeys &tk, size_t b0, uint8_t *s_code, uint8_t *s_c) {
+    TextRaw r;
+    text_fetch(tk, b0, r);
+    for (int i = threadIdx.x; i < 256; i += RS_BLOCK) s_code[i] = tk.code[i];
+    __syncthreads();
+    text_stage(tk, b0, r, s_code, s_c);
 }
 
 template <class Sink>  // sink(position inside the tile, key)
@@ -121,188 +151,175 @@ __device__ __forceinline__ void text_tile_keys(const TextKeys &tk, size_t b0, ui
     }
 }
 
-// 16 private copies of the histogram (copy = lane mod 16): text digits are skewed, and LDS atomics of one wave instruction that
-// hit the same address are serialised; spreading them over copies cuts that contention up to 16 x.
+// ---- histograms: one workgroup per CHUNK of consecutive tiles ------------------------------------------------------------------------
+// The scatter needs, for every (tile, digit), the global index of the tile's first pair with that digit
+//      = (pairs with smaller digits) + (pairs with this digit in earlier chunks) + (pairs with this digit in earlier tiles of the chunk).
+// A workgroup walks the tiles of its chunk in order and keeps ONE cumulative histogram in LDS (16 copies per digit, never cleared):
+// after the tile's 4096 atomics the sum over the copies is the count up to and including this tile -- what the NEXT tile needs as its
+// third term (tile_pre), written straight away; the last sum is the chunk's total (chunk_sum, and added to digit_total[digit]).  One
+// small kernel (k_radix_scan) turns chunk_sum into the first two terms.  Round 2's form (a histogram workgroup per tile that cleared and
+// reduced its 16 copies -- as many LDS accesses as the counting itself -- and three scan kernels that read the 1 KiB-per-tile table once
+// and rewrote it once) cost 0.087 + 0.037 ms per pass of 1e8 pairs; this one reads the digits once and writes the table once.
+// Layout h[digit][copy], copy = lane mod 16: the bank of a counter is 16 (digit mod 2) + copy, so the 32 lanes of an LDS cycle meet at
+// most two to a bank whatever the digits are (h[copy][digit] put digit mod 32 in charge: three to four deep on uniform digits); skewed
+// digits still spread over the 16 copies.
 constexpr int RS_HCOPIES = 16;
+enum HistSource : int { HS_KEYS = 0, HS_PAIRS = 1, HS_PLANE = 2, HS_TEXT = 3 };
 
-template <bool PAIRS, bool TEXT = false>
+// sum of the 16 copies of this thread's digit: four 16-byte reads, rotated so that the 16 lanes of an LDS cycle cover all 64 banks
+__device__ __forceinline__ uint32_t hist_copies_sum(const uint32_t *h, int d) {
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(h + d * RS_HCOPIES + 4 * ((j + (d >> 2)) & 3));
+        sum += v.x + v.y + v.z + v.w;
+    }
+    return sum;
+}
+
+template <int SRC>
 __global__ __launch_bounds__(RS_BLOCK) void k_radix_hist(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ hi,
-                                                          const uint32_t *__restrict__ lo, size_t n, int shift,
-                                                          uint32_t *__restrict__ tile_hist, TextKeys tk) {
-    __shared__ uint32_t h[RS_HCOPIES][256];
-    __shared__ __attribute__((aligned(16))) uint8_t s_c[TEXT ? RS_TILE + RS_TEXT_AHEAD + 16 : 16];
-    __shared__ uint8_t s_code[TEXT ? 256 : 4];
+                                                          const uint32_t *__restrict__ lo, const uint8_t *__restrict__ plane, size_t n, int shift,
+                                                          uint32_t ntiles, uint32_t tiles_per_chunk, uint32_t *__restrict__ tile_pre,
+                                                          uint32_t *__restrict__ chunk_sum, uint32_t *__restrict__ digit_total, TextKeys tk) {
+    static_assert(RS_BLOCK == 256, "one thread per digit");
+    __shared__ __attribute__((aligned(16))) uint32_t h[256 * RS_HCOPIES];
+    __shared__ __attribute__((aligned(16))) uint8_t s_c[SRC == HS_TEXT ? RS_TILE + RS_TEXT_AHEAD + 16 : 16];
+    __shared__ uint8_t s_code[SRC == HS_TEXT ? 256 : 4];
     const int tid = threadIdx.x;
-    for (int i = tid; i < RS_HCOPIES * 256; i += RS_BLOCK) (&h[0][0])[i] = 0;
-    __syncthreads();
-    uint32_t *mine = h[tid & (RS_HCOPIES - 1)];
-    const size_t base = static_cast<size_t>(blockIdx.x) * RS_TILE;
-    if (TEXT) {
-        // The first pass sorts by the lowest eight sorted bits of the key = the low eight bits of the packed window of spk codes: only the
-        // last ceil(8 / bits) symbols of the window reach them, so the digit slides along the staged codes in three instructions per
-        // position -- no key is built (the scatter builds them).  `shift` is the bit the sorted part of the key starts at.
-        text_stage_codes(tk, base, s_code, s_c);
-        const int p0 = tid * RS_KPT, bits = tk.bits, spk = tk.spk;
-        const int last = (8 + bits - 1) / bits < spk ? (8 + bits - 1) / bits : spk;  // symbols that reach the digit
-        const uint32_t dmask = spk * bits >= 8 ? 0xFFu : (1u << (spk * bits)) - 1u;  // (a window shorter than the digit)
-        uint32_t w = 0;
-        for (int j = spk - last; j < spk; ++j) w = (w << bits) | s_c[p0 + j];
+    for (int i = tid; i < 256 * RS_HCOPIES; i += RS_BLOCK) h[i] = 0;
+    if (SRC == HS_TEXT) s_code[tid] = tk.code[tid];
+    uint32_t *mine = h + (tid & (RS_HCOPIES - 1));  // counter of digit d: mine[d * RS_HCOPIES]
+    const uint32_t t0 = blockIdx.x * tiles_per_chunk;
+    const uint32_t t1 = t0 + tiles_per_chunk < ntiles ? t0 + tiles_per_chunk : ntiles;
+    const bool plane_aligned = SRC == HS_PLANE && (reinterpret_cast<uintptr_t>(plane) & 15) == 0;
+    // PLANE / KEYS: the next tile's digits are asked for before the current tile is counted
+    uint4 ahead[SRC == HS_KEYS ? RS_KPT / 2 : 1];
+    auto fetch = [&](uint32_t t) {
+        const size_t base = static_cast<size_t>(t) * RS_TILE;
+        if (SRC == HS_PLANE) {
+            if (plane_aligned && base + RS_TILE <= n) ahead[0] = reinterpret_cast<const uint4 *>(plane + base)[tid];
+        } else if (SRC == HS_KEYS) {
+            if (base + RS_TILE <= n) {
+                const uint4 *p = reinterpret_cast<const uint4 *>(keys + base);
 #pragma unroll
-        for (int g = 0; g < RS_KPT; ++g) {
-            if (base + p0 + g < n) atomicAdd(&mine[w & dmask], 1u);
-            w = (w << bits) | s_c[p0 + spk + g];
+                for (int k = 0; k < RS_KPT / 2; ++k) ahead[k] = p[k * RS_BLOCK + tid];
+            }
         }
-    } else if (!PAIRS && base + RS_TILE <= n) {  // full tile: two keys per 16-byte load (order inside the tile is irrelevant here)
-        const uint4 *p = reinterpret_cast<const uint4 *>(keys + base);
-#pragma unroll
-        for (int k = 0; k < RS_KPT / 2; ++k) {
-            const uint4 v = p[k * RS_BLOCK + tid];
-            const uint64_t k0 = (static_cast<uint64_t>(v.y) << 32) | v.x, k1 = (static_cast<uint64_t>(v.w) << 32) | v.z;
-            atomicAdd(&mine[digit_of(k0, shift)], 1u);
-            atomicAdd(&mine[digit_of(k1, shift)], 1u);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < RS_KPT; ++k) {
-            const size_t i = base + static_cast<size_t>(k) * RS_BLOCK + tid;
-            if (i < n) atomicAdd(&mine[digit_of(load_key<PAIRS>(keys, hi, lo, i), shift)], 1u);
-        }
+    };
+    TextRaw text_ahead;  // TEXT: the same for the raw bytes of the text
+    if (t0 < t1) {
+        if (SRC == HS_TEXT) text_fetch(tk, static_cast<size_t>(t0) * RS_TILE, text_ahead); else fetch(t0);
     }
     __syncthreads();
-    if (tid < 256) {
-        uint32_t sum = 0;
+    uint32_t before = 0;  // pairs with this thread's digit in the chunk's tiles so far
+    for (uint32_t t = t0; t < t1; ++t) {
+        const size_t base = static_cast<size_t>(t) * RS_TILE;
+        if (SRC == HS_TEXT) {
+            // The first pass sorts by the lowest eight sorted bits of the key = the low eight bits of the packed window of spk codes: only the
+            // last ceil(8 / bits) symbols of the window reach them, so the digit slides along the staged codes in three instructions per
+            // position -- no key is built (the scatter builds them).
+            const TextRaw raw = text_ahead;
+            if (t + 1 < t1) text_fetch(tk, base + RS_TILE, text_ahead);
+            text_stage(tk, base, raw, s_code, s_c);
+            const int p0 = tid * RS_KPT, bits = tk.bits, spk = tk.spk;
+            const int last = (8 + bits - 1) / bits < spk ? (8 + bits - 1) / bits : spk;  // symbols that reach the digit (<= 8)
+            const uint32_t dmask = spk * bits >= 8 ? 0xFFu : (1u << (spk * bits)) - 1u;  // (a window shorter than the digit)
+            // the 24 codes from position p0 + spk - last on, in three registers (aligned 8-byte LDS reads, a byte at a time would put the
+            // 32 lanes of an LDS cycle four deep on eight banks): `last` codes prime the window, one enters per position
+            const int off = p0 + spk - last;
+            const uint64_t *q = reinterpret_cast<const uint64_t *>(s_c + (off & ~7));
+            const unsigned sh = static_cast<unsigned>(off & 7) * 8u;
+            const uint64_t a = q[0], b = q[1], c = q[2], e = q[3];
+            const uint64_t c0 = sh ? (a >> sh) | (b << (64u - sh)) : a, c1 = sh ? (b >> sh) | (c << (64u - sh)) : b, c2 = sh ? (c >> sh) | (e << (64u - sh)) : c;
+            auto code_at = [&](int j) -> uint32_t { return static_cast<uint32_t>((j < 8 ? c0 : j < 16 ? c1 : c2) >> (8 * (j & 7))) & 0xFFu; };
+            uint32_t w = 0;
+            for (int j = 0; j < last; ++j) w = (w << bits) | code_at(j);
 #pragma unroll
-        for (int c = 0; c < RS_HCOPIES; ++c) sum += h[c][tid];
-        tile_hist[static_cast<size_t>(blockIdx.x) * 256 + tid] = sum;
+            for (int g = 0; g < RS_KPT; ++g) {
+                if (base + p0 + g < n) atomicAdd(&mine[(w & dmask) * RS_HCOPIES], 1u);
+                w = (w << bits) | code_at(last + g);
+            }
+        } else if (SRC == HS_PLANE && plane_aligned && base + RS_TILE <= n) {
+            const uint4 v = ahead[0];
+            if (t + 1 < t1) fetch(t + 1);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) atomicAdd(&mine[((w[k] >> (8 * b)) & 0xFFu) * RS_HCOPIES], 1u);
+            }
+        } else if (SRC == HS_KEYS && base + RS_TILE <= n) {  // full tile: two keys per 16-byte load (order inside the tile is irrelevant here)
+            uint4 v[RS_KPT / 2];
+#pragma unroll
+            for (int k = 0; k < RS_KPT / 2; ++k) v[k] = ahead[k];
+            if (t + 1 < t1) fetch(t + 1);
+#pragma unroll
+            for (int k = 0; k < RS_KPT / 2; ++k) {
+                const uint64_t k0 = (static_cast<uint64_t>(v[k].y) << 32) | v[k].x, k1 = (static_cast<uint64_t>(v[k].w) << 32) | v[k].z;
+                atomicAdd(&mine[digit_of(k0, shift) * RS_HCOPIES], 1u);
+                atomicAdd(&mine[digit_of(k1, shift) * RS_HCOPIES], 1u);
+            }
+        } else {  // pairs, a last partial tile, an unaligned plane
+#pragma unroll
+            for (int k = 0; k < RS_KPT; ++k) {
+                const size_t i = base + static_cast<size_t>(k) * RS_BLOCK + tid;
+                if (i < n) {
+                    const uint32_t d = SRC == HS_PLANE ? plane[i] : digit_of(load_key<SRC == HS_PAIRS>(keys, hi, lo, i), shift);
+                    atomicAdd(&mine[d * RS_HCOPIES], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t upto = hist_copies_sum(h, tid);
+        tile_pre[static_cast<size_t>(t) * 256 + tid] = before;
+        before = upto;
+        __syncthreads();  // (the next tile's atomics must not reach a counter before its sum has been read)
+    }
+    if (t0 < t1) {
+        chunk_sum[static_cast<size_t>(blockIdx.x) * 256 + tid] = before;
+        if (before) atomicAdd(&digit_total[tid], before);
     }
 }
 
-// The same histograms from the DIGIT PLANE the previous pass's scatter left behind: one byte per pair (the digit this pass sorts by, in
-// the order this pass reads the pairs) instead of the eight bytes of the key -- the histogram pass is a pure streaming read, and seven
-// of its eight bytes were never looked at.
-__global__ __launch_bounds__(RS_BLOCK) void k_radix_hist_plane(const uint8_t *__restrict__ plane, size_t n, uint32_t *__restrict__ tile_hist) {
-    __shared__ uint32_t h[RS_HCOPIES][256];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < RS_HCOPIES * 256; i += RS_BLOCK) (&h[0][0])[i] = 0;
-    __syncthreads();
-    uint32_t *mine = h[tid & (RS_HCOPIES - 1)];
-    const size_t base = static_cast<size_t>(blockIdx.x) * RS_TILE;
-    static_assert(RS_TILE == RS_BLOCK * 16, "one 16-byte load per thread");
-    if (base + RS_TILE <= n && (reinterpret_cast<uintptr_t>(plane) & 15) == 0) {
-        const uint4 v = reinterpret_cast<const uint4 *>(plane + base)[tid];
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) atomicAdd(&mine[(w[k] >> (8 * b)) & 0xFFu], 1u);
-        }
-    } else {
-        for (int k = 0; k < 16; ++k) {
-            const size_t i = base + static_cast<size_t>(k) * RS_BLOCK + tid;
-            if (i < n) atomicAdd(&mine[plane[i]], 1u);
-        }
+// chunk_sum[g][d]: pairs with digit d in chunk g  ->  pairs with a smaller digit + pairs with digit d in earlier chunks.  One wave per
+// digit (256 workgroups of one wave: a lane's loads go to rows 1 KiB apart, 64 lines per instruction -- spread over all CUs they cost
+// nothing, on 16 CUs they were the kernel's whole time), lane = a stretch of at most RS_MAX_CHUNKS / 64 chunks (registers), one DPP scan
+// across the lanes.  digit_total[d] = sum over the chunks (the histogram workgroups added it up).
+#ifndef DK_RS_MAX_CHUNKS
+#define DK_RS_MAX_CHUNKS 1024
+#endif
+constexpr int RS_MAX_CHUNKS = DK_RS_MAX_CHUNKS;
+__global__ __launch_bounds__(64) void k_radix_scan(uint32_t *__restrict__ chunk_sum, uint32_t nchunks, const uint32_t *__restrict__ digit_total) {
+    const int lane = threadIdx.x, d = blockIdx.x;
+    uint32_t smaller = 0;
+    {
+        const uint4 t = reinterpret_cast<const uint4 *>(digit_total)[lane];  // digits 4 lane .. 4 lane + 3
+        smaller = (lane * 4 < d ? t.x : 0u) + (lane * 4 + 1 < d ? t.y : 0u) + (lane * 4 + 2 < d ? t.z : 0u) + (lane * 4 + 3 < d ? t.w : 0u);
     }
-    __syncthreads();
-    if (tid < 256) {
-        uint32_t sum = 0;
+    const uint32_t per = (nchunks + 63u) / 64u;
+    const uint32_t g0 = static_cast<uint32_t>(lane) * per;
+    uint32_t v[RS_MAX_CHUNKS / 64], sum = 0;
 #pragma unroll
-        for (int c = 0; c < RS_HCOPIES; ++c) sum += h[c][tid];
-        tile_hist[static_cast<size_t>(blockIdx.x) * 256 + tid] = sum;
+    for (int k = 0; k < RS_MAX_CHUNKS / 64; ++k) {
+        const uint32_t g = g0 + k;
+        v[k] = (static_cast<uint32_t>(k) < per && g < nchunks) ? chunk_sum[static_cast<size_t>(g) * 256 + d] : 0u;
+        sum += v[k];
     }
-}
-
-// phase A: per chunk of tiles, per digit: sum of the tile counts
-__global__ __launch_bounds__(256) void k_radix_scan_a(const uint32_t *__restrict__ tile_hist, size_t ntiles,
-                                                       size_t tiles_per_chunk, uint32_t *__restrict__ chunk_sum) {
-    const size_t g = blockIdx.x;
-    const int d = threadIdx.x;
-    const size_t t0 = g * tiles_per_chunk;
-    const size_t t1 = t0 + tiles_per_chunk < ntiles ? t0 + tiles_per_chunk : ntiles;
-    uint32_t s = 0;
-#pragma unroll 8
-    for (size_t t = t0; t < t1; ++t) s += tile_hist[t * 256 + d];
-    chunk_sum[g * 256 + d] = s;
-}
-// phase B (one workgroup of 1024): digit-major exclusive scan of the chunk sums; 4 threads share a digit's column.  Eight rows are
-// loaded before any is rewritten, so that the loads are in flight together.  (All 64 rows of a thread in registers at once was slower:
-// 39 against 16 us -- the guarded 64-entry array went to scratch.)
-__global__ __launch_bounds__(1024) void k_radix_scan_b(uint32_t *__restrict__ chunk_sum, size_t nchunks) {
-    __shared__ uint32_t s_tmp[16 + 1];
-    __shared__ uint32_t s_part[4][256];
-    const int d = threadIdx.x & 255, part = threadIdx.x >> 8;
-    const size_t q = (nchunks + 3) / 4;
-    const size_t g0 = part * q, g1 = g0 + q < nchunks ? g0 + q : nchunks;
-    uint32_t run = 0;
-    for (size_t g = g0; g < g1; g += 8) {
-        uint32_t v[8];
+    smaller = wave_sum(smaller);
+    uint32_t run = smaller + wave_incl_sum(sum, lane) - sum;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = g + k < g1 ? chunk_sum[(g + k) * 256 + d] : 0u;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (g + k < g1) chunk_sum[(g + k) * 256 + d] = run;
-            run += v[k];
-        }
-    }
-    s_part[part][d] = run;
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const uint32_t t = s_part[p][d];
-        if (p < part) before += t;
-        total += t;
-    }
-    // exclusive scan of the digit totals over d: only the part-0 threads carry a value
-    const uint32_t base = block_excl_sum<16>(part == 0 ? total : 0u, s_tmp, nullptr);
-    if (part == 0) s_part[0][d] = base;
-    __syncthreads();
-    const uint32_t off = s_part[0][d] + before;
-    for (size_t g = g0; g < g1; g += 8) {
-        uint32_t v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = g + k < g1 ? chunk_sum[(g + k) * 256 + d] : 0u;
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (g + k < g1) chunk_sum[(g + k) * 256 + d] = v[k] + off;
-    }
-}
-// all three phases in one workgroup, for sorts of few tiles (the big-group lists: a launch costs more than this loop)
-__global__ __launch_bounds__(256) void k_radix_scan_small(uint32_t *__restrict__ tile_hist, size_t ntiles) {
-    __shared__ uint32_t s_tmp[4 + 1];
-    const int d = threadIdx.x;
-    uint32_t run = 0;
-#pragma unroll 8
-    for (size_t t = 0; t < ntiles; ++t) {
-        const uint32_t v = tile_hist[t * 256 + d];
-        tile_hist[t * 256 + d] = run;
-        run += v;
-    }
-    const uint32_t base = block_excl_sum<4>(run, s_tmp, nullptr);
-#pragma unroll 8
-    for (size_t t = 0; t < ntiles; ++t) tile_hist[t * 256 + d] += base;
-}
-
-// phase C: tile counts -> exclusive global offsets (eight rows loaded before any is rewritten: the loads are in flight together)
-__global__ __launch_bounds__(256) void k_radix_scan_c(uint32_t *__restrict__ tile_hist, size_t ntiles, size_t tiles_per_chunk,
-                                                       const uint32_t *__restrict__ chunk_sum) {
-    const size_t g = blockIdx.x;
-    const int d = threadIdx.x;
-    const size_t t0 = g * tiles_per_chunk;
-    const size_t t1 = t0 + tiles_per_chunk < ntiles ? t0 + tiles_per_chunk : ntiles;
-    uint32_t run = chunk_sum[g * 256 + d];
-    for (size_t t = t0; t < t1; t += 8) {
-        uint32_t v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = t + k < t1 ? tile_hist[(t + k) * 256 + d] : 0u;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (t + k < t1) tile_hist[(t + k) * 256 + d] = run;
-            run += v[k];
-        }
+    for (int k = 0; k < RS_MAX_CHUNKS / 64; ++k) {
+        const uint32_t g = g0 + k;
+        if (static_cast<uint32_t>(k) < per && g < nchunks) chunk_sum[static_cast<size_t>(g) * 256 + d] = run;
+        run += v[k];
     }
 }
 
-// tile_offs: the scanned per-tile digit offsets.  next_digit (may be null): the digit plane for the next pass (k_radix_hist_plane).  xcd_tiles != 0: XCD-aware tile order over a grid of 8 * ceil(ntiles / 8) blocks.
+// The offsets of a pass: tile_pre / chunk_base as above, chunk = tile / tiles_per_chunk.
+struct TileOffsets { const uint32_t *tile_pre; const uint32_t *chunk_base; uint32_t tiles_per_chunk; };
+
+// offs: where the tile's pairs of every digit go (TileOffsets).  next_digit (may be null): the digit plane for the next pass (k_radix_hist_plane).  xcd_tiles != 0: XCD-aware tile order over a grid of 8 * ceil(ntiles / 8) blocks.
 // Three workgroups per CU, not the four that registers and LDS would allow: with a fourth tile in flight per CU the L2 no longer
 // merges the short output runs of neighbouring tiles before it has to evict them (measured, 1e8 text: 3.95 ms of scatter per sort
 // against 3.6 ms; two per CU: 3.65 ms but slower overall).  The kernel is bound by that, not by its ballots: a third fewer vector
@@ -311,7 +328,7 @@ template <bool PAIRS = false, bool TEXT = false>
 __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_radix_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                              const uint32_t *__restrict__ pair_lo,
                                                              uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n,
-                                                             int shift, const uint32_t *__restrict__ tile_offs, uint32_t xcd_tiles,
+                                                             int shift, TileOffsets offs, uint32_t xcd_tiles,
                                                              TextKeys tk, uint8_t *__restrict__ next_digit, SortFinalOut fin) {
     __shared__ uint64_t s_keys[RS_TILE];          // tile of keys in digit order; reused for the values
     // per-wave digit counters (then exclusive over waves) | tile-local start of each digit | global offset of the digit minus its
@@ -336,10 +353,13 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))
     const size_t left = n - tile_base;
     const uint32_t valid = left < static_cast<size_t>(RS_TILE) ? static_cast<uint32_t>(left) : RS_TILE;
     // the tile's global digit offsets are needed after the ranking only: asked for here, their latency hides behind it
-    const uint32_t goff_early = tid < 256 ? tile_offs[static_cast<size_t>(tile) * 256 + tid] : 0u;
+    const uint32_t goff_early = tid < 256 ? offs.chunk_base[static_cast<size_t>(tile / offs.tiles_per_chunk) * 256 + tid] + offs.tile_pre[static_cast<size_t>(tile) * 256 + tid] : 0u;
 
+    // TEXT: a thread builds the keys of 16 consecutive positions, so the lanes of one LDS store are 128 bytes apart -- all on one pair of
+    // banks.  Position o is kept at o with its low four bits rotated by the thread's number: conflict-free both ways.
+    auto swz = [](uint32_t o) { return (o & ~15u) | ((o + (o >> 4)) & 15u); };
     if (TEXT) {  // keys of the tile, in position order
-        text_tile_keys(tk, tile_base, s_code, reinterpret_cast<uint8_t *>(s_tab), [&](int o, uint64_t key) { s_keys[o] = key; });
+        text_tile_keys(tk, tile_base, s_code, reinterpret_cast<uint8_t *>(s_tab), [&](int o, uint64_t key) { s_keys[swz(static_cast<uint32_t>(o))] = key; });
         __syncthreads();
     } else {
         for (int i = tid; i < RS_WAVES * 256; i += RS_BLOCK) s_tab[i] = 0;
@@ -354,7 +374,7 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))
     for (int k = 0; k < RS_KPT; ++k) {
         const uint32_t li = wbase + k * 64 + lane;
         if (li < valid) {
-            key[k] = TEXT ? s_keys[li] : load_key<PAIRS>(kin, vin, pair_lo, tile_base + li);  // PAIRS: vin holds the high words
+            key[k] = TEXT ? s_keys[swz(li)] : load_key<PAIRS>(kin, vin, pair_lo, tile_base + li);  // PAIRS: vin holds the high words
             val[k] = TEXT ? static_cast<uint32_t>(tile_base + li) : (PAIRS ? 0u : vin[tile_base + li]);
         } else {
             key[k] = ~0ull;  // padding sorts behind every real pair of the tile and is never written
@@ -531,58 +551,68 @@ __global__ __launch_bounds__(SS_BLOCK) void k_radix_sort_small(uint64_t *__restr
 // 56 bits in six passes, 40 bits in four): every pass got 1.6 x slower -- 1024 digits cut a tile's output into runs of four pairs
 // (32 bytes of keys, 16 of values), more partial lines than the L2 merges -- 2^28 ACGT 17.5 against 13.4 ms, 1e8 text 15.2 against
 // 14.0 ms (profiles/r03_wide_digit_experiment.log).  Removed; eight bits per pass stay.
+// chunking of a sort of ntiles tiles: at most RS_MAX_CHUNKS histogram workgroups, every one walking tiles_per_chunk consecutive tiles
+struct ChunkPlan { uint32_t ntiles, tiles_per_chunk, nchunks; };
+static ChunkPlan plan_chunks(size_t count) {
+    ChunkPlan p;
+    p.ntiles = static_cast<uint32_t>(div_up(count, RS_TILE));
+    p.tiles_per_chunk = static_cast<uint32_t>(div_up(p.ntiles, RS_MAX_CHUNKS));
+    p.nchunks = static_cast<uint32_t>(div_up(p.ntiles, p.tiles_per_chunk));
+    return p;
+}
+
 static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
                               int begin_bit, int end_bit, const TextKeys *text, const SortFinalOut *final_out) {
-    const size_t ntiles = div_up(count, RS_TILE);
-    const size_t tiles_per_chunk = div_up(ntiles, RS_MAX_CHUNKS);
-    const size_t nchunks = div_up(ntiles, tiles_per_chunk);
+    const ChunkPlan cp = plan_chunks(count);
+    const size_t ntiles = cp.ntiles;
+    const int npasses = (end_bit - begin_bit + 7) / 8;
     const size_t mark = ctx->ws_mark();
-    uint32_t *tile_hist = ctx->ws_alloc<uint32_t>(ntiles * 256);
-    uint32_t *chunk_sum = ctx->ws_alloc<uint32_t>(nchunks * 256);
-    // digit plane: every scatter but the last leaves the next pass's digits behind, one byte per pair.  The histograms get 2x faster,
+    uint32_t *tile_pre = ctx->ws_alloc<uint32_t>(ntiles * 256);
+    uint32_t *chunk_sum = ctx->ws_alloc<uint32_t>(static_cast<size_t>(cp.nchunks) * 256);
+    uint32_t *digit_total = ctx->ws_alloc<uint32_t>(static_cast<size_t>(npasses) * 256);  // one row per pass, cleared once
+    // digit plane: every scatter but the last leaves the next pass's digits behind, one byte per pair.  The histograms get faster,
     // the scatters 10 % slower (the plane's 16-byte runs cost as many L2 write requests as the 64-byte runs of the values).  Net gain,
     // round 3: 2.7 % of the whole suffix sort at 1e8 pairs (12.07 -> 11.74 ms), 1.8 % at 2^28; on from 2^26 pairs, where the keys
     // (8 bytes per pair) no longer fit the 256 MiB Infinity Cache.
     const int plane_mode = DK_KNOB("DK_DIGIT_PLANE", -1);  // tuning build: 1 / 0 = always (from 2^20 pairs) / never
     const size_t plane_from = plane_mode == 1 ? (size_t(1) << 20) : (size_t(1) << 26);
     uint8_t *plane = plane_mode != 0 && end_bit - begin_bit > 8 && count >= plane_from ? ctx->ws_try_alloc<uint8_t>(count) : nullptr;  // optional: the sort runs without it
-    if (!tile_hist || !chunk_sum) return DK_E_NOMEM;
+    if (!tile_pre || !chunk_sum || !digit_total) return DK_E_NOMEM;
     hipStream_t st = ctx->stream;
-    for (int shift = begin_bit; shift < end_bit; shift += 8) {
+    DK_HIP(ctx, hipMemsetAsync(digit_total, 0, static_cast<size_t>(npasses) * 256 * sizeof(uint32_t), st));
+    const TileOffsets offs{tile_pre, chunk_sum, cp.tiles_per_chunk};
+    int pass = 0;
+    for (int shift = begin_bit; shift < end_bit; shift += 8, ++pass) {
         const bool have_plane = plane && shift > begin_bit;      // written by the previous pass
         uint8_t *emit = plane && shift + 8 < end_bit ? plane : nullptr;  // read by the next one
         const TextKeys *tk = text && shift == begin_bit ? text : nullptr;
         const bool last = shift + 8 >= end_bit;
         const SortFinalOut fin = last && final_out ? *final_out : SortFinalOut{};
         uint32_t *vout = fin.vals ? fin.vals : vals_alt;
+        uint32_t *totals = digit_total + static_cast<size_t>(pass) * 256;
         {
-            LaunchScope ls(ctx, tk ? K_RADIX_HIST_TEXT : K_RADIX_HIST, (tk ? 1.0 : have_plane ? 1.0 : 8.0) * count);
+            LaunchScope ls(ctx, tk ? K_RADIX_HIST_TEXT : K_RADIX_HIST, (tk ? 1.0 : have_plane ? 1.0 : 8.0) * count + 1024.0 * ntiles);
+            const dim3 grid(cp.nchunks), block(RS_BLOCK);
             if (tk)
-                k_radix_hist<false, true><<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(nullptr, nullptr, nullptr, count, shift, tile_hist, *tk);
+                k_radix_hist<HS_TEXT><<<grid, block, 0, st>>>(nullptr, nullptr, nullptr, nullptr, count, shift, cp.ntiles, cp.tiles_per_chunk, tile_pre, chunk_sum, totals, *tk);
             else if (have_plane)
-                k_radix_hist_plane<<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(plane, count, tile_hist);
+                k_radix_hist<HS_PLANE><<<grid, block, 0, st>>>(nullptr, nullptr, nullptr, plane, count, shift, cp.ntiles, cp.tiles_per_chunk, tile_pre, chunk_sum, totals, TextKeys{});
             else
-                k_radix_hist<false><<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(keys, nullptr, nullptr, count, shift, tile_hist, TextKeys{});
+                k_radix_hist<HS_KEYS><<<grid, block, 0, st>>>(keys, nullptr, nullptr, nullptr, count, shift, cp.ntiles, cp.tiles_per_chunk, tile_pre, chunk_sum, totals, TextKeys{});
         }
         {
-            LaunchScope ls(ctx, K_RADIX_SCAN, 3.0 * 1024.0 * ntiles);
-            if (ntiles <= 1024) {
-                k_radix_scan_small<<<dim3(1), dim3(256), 0, st>>>(tile_hist, ntiles);
-            } else {
-                k_radix_scan_a<<<dim3(nchunks), dim3(256), 0, st>>>(tile_hist, ntiles, tiles_per_chunk, chunk_sum);
-                k_radix_scan_b<<<dim3(1), dim3(1024), 0, st>>>(chunk_sum, nchunks);
-                k_radix_scan_c<<<dim3(nchunks), dim3(256), 0, st>>>(tile_hist, ntiles, tiles_per_chunk, chunk_sum);
-            }
+            LaunchScope ls(ctx, K_RADIX_SCAN, 2.0 * 1024.0 * cp.nchunks);
+            k_radix_scan<<<dim3(256), dim3(64), 0, st>>>(chunk_sum, cp.nchunks, totals);
         }
         {
             LaunchScope ls(ctx, tk ? K_RADIX_SCATTER_TEXT : K_RADIX_SCATTER, ((tk ? 13.0 : 24.0) + (emit ? 1.0 : 0.0) + (fin.bwt ? 1.0 : 0.0)) * count);
             const bool xcd = DK_KNOB("DK_XCD", 1) != 0;
             const size_t grid = xcd ? 8 * div_up(ntiles, 8) : ntiles;
             if (tk)
-                k_radix_scatter<false, true><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(nullptr, nullptr, nullptr, keys_alt, vout, count, shift, tile_hist,
+                k_radix_scatter<false, true><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(nullptr, nullptr, nullptr, keys_alt, vout, count, shift, offs,
                                                                                    xcd ? static_cast<uint32_t>(ntiles) : 0u, *tk, emit, fin);
             else
-                k_radix_scatter<false><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(keys, vals, nullptr, keys_alt, vout, count, shift, tile_hist,
+                k_radix_scatter<false><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(keys, vals, nullptr, keys_alt, vout, count, shift, offs,
                                                                              xcd ? static_cast<uint32_t>(ntiles) : 0u, TextKeys{}, emit, fin);
         }
         DK_HIP(ctx, hipGetLastError());
@@ -789,30 +819,30 @@ int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, 
                          uint64_t *scratch_b, uint32_t *dst) {
     if (count == 0) return DK_OK;
     if (!val && count == limit && count <= ISA_MAX_N && scratch_b) return inverse_permutation_windows(ctx, idx, count, scratch, scratch_b, dst);
-    const size_t ntiles = div_up(count, RS_TILE);
-    const size_t tiles_per_chunk = div_up(ntiles, RS_MAX_CHUNKS);
-    const size_t nchunks = div_up(ntiles, tiles_per_chunk);
+    const ChunkPlan cp = plan_chunks(count);
+    const size_t ntiles = cp.ntiles;
     const size_t mark = ctx->ws_mark();
-    uint32_t *tile_hist = ctx->ws_alloc<uint32_t>(ntiles * 256);
-    uint32_t *chunk_sum = ctx->ws_alloc<uint32_t>(nchunks * 256);
-    if (!tile_hist || !chunk_sum) return DK_E_NOMEM;
+    uint32_t *tile_pre = ctx->ws_alloc<uint32_t>(ntiles * 256);
+    uint32_t *chunk_sum = ctx->ws_alloc<uint32_t>(static_cast<size_t>(cp.nchunks) * 256);
+    uint32_t *digit_total = ctx->ws_alloc<uint32_t>(256);
+    if (!tile_pre || !chunk_sum || !digit_total) return DK_E_NOMEM;
     hipStream_t st = ctx->stream;
+    DK_HIP(ctx, hipMemsetAsync(digit_total, 0, 256 * sizeof(uint32_t), st));
     const unsigned lb = ceil_log2_u64(limit);
     const int shift = 32 + static_cast<int>(lb > 8 ? lb - 8 : 0);
     const size_t grid = 8 * div_up(ntiles, 8);
     {
         LaunchScope ls(ctx, K_RADIX_HIST, 8.0 * count);
-        k_radix_hist<true><<<dim3(ntiles), dim3(RS_BLOCK), 0, st>>>(nullptr, idx, val, count, shift, tile_hist, TextKeys{});
+        k_radix_hist<HS_PAIRS><<<dim3(cp.nchunks), dim3(RS_BLOCK), 0, st>>>(nullptr, idx, val, nullptr, count, shift, cp.ntiles, cp.tiles_per_chunk, tile_pre, chunk_sum,
+                                                                          digit_total, TextKeys{});
     }
     {
-        LaunchScope ls(ctx, K_RADIX_SCAN, 3.0 * 1024.0 * ntiles);
-        k_radix_scan_a<<<dim3(nchunks), dim3(256), 0, st>>>(tile_hist, ntiles, tiles_per_chunk, chunk_sum);
-        k_radix_scan_b<<<dim3(1), dim3(1024), 0, st>>>(chunk_sum, nchunks);
-        k_radix_scan_c<<<dim3(nchunks), dim3(256), 0, st>>>(tile_hist, ntiles, tiles_per_chunk, chunk_sum);
+        LaunchScope ls(ctx, K_RADIX_SCAN, 2.0 * 1024.0 * cp.nchunks);
+        k_radix_scan<<<dim3(256), dim3(64), 0, st>>>(chunk_sum, cp.nchunks, digit_total);
     }
     {
         LaunchScope ls(ctx, K_RADIX_SCATTER, 16.0 * count);
-        k_radix_scatter<true><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(nullptr, idx, val, scratch, nullptr, count, shift, tile_hist,
+        k_radix_scatter<true><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(nullptr, idx, val, scratch, nullptr, count, shift, TileOffsets{tile_pre, chunk_sum, cp.tiles_per_chunk},
                                                                        static_cast<uint32_t>(ntiles), TextKeys{}, nullptr, SortFinalOut{});
     }
     {

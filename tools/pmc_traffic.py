@@ -21,15 +21,14 @@ import re
 import sys
 
 # kernels whose reads are random narrow gathers: one 64-byte request per access, FETCH_SIZE is taken as reported
-GATHER_KERNELS = {"k_round_local", "k_plateau_sort", "k_plateau_ranks", "k_bwt_gather", "k_radix_scan_a", "k_radix_scan_b", "k_radix_scan_c",
+GATHER_KERNELS = {"k_round_local", "k_plateau_sort", "k_plateau_ranks", "k_bwt_gather", "k_radix_scan",
                   "k_big_reduce", "k_big_spine", "k_big_apply", "k_big_back", "k_rerank_scan", "k_dc_carry_a", "k_dc_carry_b", "k_dc_carry_c",
                   "k_dc_runscan", "k_dc_sweep", "k_fill_u32", "k_place_active", "k_rank_active", "k_prefix_probe", "k_to_inplace",
-                  "k_plateau_scan", "k_radix_scan_small", "k_ibwt_walk", "k_ibwt_emit", "k_ibwt_jump", "k_isa_init"}
+                  "k_plateau_scan", "k_ibwt_walk", "k_ibwt_emit", "k_ibwt_jump", "k_isa_init"}
 
 # dk_stats slot (dark_amd/csrc/context.hpp) of every kernel: a slot is named after its kernel, or after the common prefix of the kernels
 # one LaunchScope brackets; bench.py reports HIP-event times per slot, the rocprofv3 CSVs are per kernel
-SLOT_OF = {"k_radix_hist_plane": "k_radix_hist", "k_radix_scan_small": "k_radix_scan", "k_radix_scan_a": "k_radix_scan", "k_radix_scan_b": "k_radix_scan", "k_radix_scan_c": "k_radix_scan",
-           "k_dc_runscan": "k_dc_carry", "k_dc_carry_a": "k_dc_carry", "k_dc_carry_b": "k_dc_carry", "k_dc_carry_c": "k_dc_carry",
+SLOT_OF = {"k_dc_runscan": "k_dc_carry", "k_dc_carry_a": "k_dc_carry", "k_dc_carry_b": "k_dc_carry", "k_dc_carry_c": "k_dc_carry",
            "k_fill_u32": "k_dc_carry", "k_ibwt_scan_a": "k_ibwt_hist", "k_ibwt_scan_b": "k_ibwt_hist", "k_ibwt_scan_c": "k_ibwt_hist",
            "k_big_reduce": "k_big_classify", "k_big_spine": "k_big_classify", "k_big_apply": "k_big_classify",
            "k_rank_active": "k_place_active", "k_to_inplace": "k_plateau_ranks", "k_plateau_count": "k_plateau_ranks",
@@ -43,7 +42,8 @@ def short(name):
         return None
     k = m.group(1)
     # the first pass of the initial sort is its own template instance (keys from the text) and its own dk_stats slot
-    if k in ("k_radix_hist", "k_radix_scatter") and m.group(2) and m.group(2).replace(" ", "") == "<false,true>":
+    args = m.group(2).replace(" ", "") if m.group(2) else ""
+    if (k == "k_radix_scatter" and args == "<false,true>") or (k == "k_radix_hist" and args == "<3>"):  # HS_TEXT = 3
         k += "_text"
     return k
 
