@@ -16,6 +16,7 @@
 //                        groups through the global sort, rerank) while groups of more than 256 members exist, then in-place rounds
 //                        (k_plateau_sort / k_plateau_ranks: no compaction, no scan, live count read back one round late)
 // Only members of unresolved groups are ever sorted again (Larsson-Sadakane style filtering).  DESIGN.md section 4.1.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -323,45 +324,35 @@ struct BwtCarry {
 };
 constexpr BwtCarry NO_CARRY{0, nullptr, nullptr, nullptr, nullptr, nullptr};
 
-// pos_in == nullptr means slot a sits at SA position a (first rerank, straight after the initial sort).
 // The flags come from k_rerank_reduce's byte array; the tile's lists arrive through LDS with lane-contiguous loads, the compacted outputs
-// leave through LDS the same way.  FIRST = (pos_in == nullptr): no position array to stage -> more workgroups per CU for the largest launch
-template <bool FIRST>
+// leave through LDS the same way.  (The first rerank, straight after the initial sort, has its own kernel below.)
 __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ idx,
                                                             const uint32_t *__restrict__ pos_in, size_t count,
                                                             const RerankAgg *__restrict__ agg, uint32_t *__restrict__ rank,
                                                             uint32_t *__restrict__ sa, uint32_t *__restrict__ out_idx,
                                                             uint32_t *__restrict__ out_pos, uint32_t *__restrict__ out_gid,
-                                                            uint32_t *__restrict__ gstart, const uint32_t *__restrict__ mail, BwtCarry bc) {
+                                                            uint32_t *__restrict__ gstart, BwtCarry bc) {
     __shared__ __attribute__((aligned(16))) uint32_t s_out[2 * RR_TILE];  // compacted idx | pos
     __shared__ __attribute__((aligned(16))) uint32_t s_idx[RR_TILE];
-    __shared__ __attribute__((aligned(16))) uint32_t s_pos[FIRST ? 4 : RR_TILE];
+    __shared__ __attribute__((aligned(16))) uint32_t s_pos[RR_TILE];
     __shared__ __attribute__((aligned(8))) uint8_t s_osym[RR_TILE];        // compacted symbols
     __shared__ uint32_t s_tmp[RR_WAVES + 1];
     const int tid = threadIdx.x;
     const size_t b0 = static_cast<size_t>(blockIdx.x) * RR_TILE;
-    if (FIRST) {
-        // The initial sort's last pass left every suffix at its slot of SA (and its symbol in L): finals need no store here, and a tile
-        // without a survivor (most tiles of random bytes and small alphabets) has nothing to compact either.
-        const uint32_t surv_before = agg[blockIdx.x].surv;
-        const uint32_t surv_after = blockIdx.x + 1 < gridDim.x ? agg[blockIdx.x + 1].surv : mail[0];
-        if (surv_before == surv_after) return;
-    }
 #pragma unroll
     for (int k = 0; k < RR_IPT; ++k) {
         const int o = k * RR_BLOCK + tid;
         const size_t a = b0 + o;
         if (a < count) {
             s_idx[o] = idx[a];
-            if (!FIRST) s_pos[o] = pos_in[a];
+            s_pos[o] = pos_in[a];
         }
     }
     const size_t a0 = b0 + static_cast<size_t>(tid) * RR_IPT;
     const uint64_t fl = *reinterpret_cast<const uint64_t *>(flags + a0);  // whole tiles are stored: zero past `count`
     uint64_t sym8 = 0;  // bc.bwt: the symbols in front of this thread's eight suffixes
     if (bc.bwt && a0 < count) {
-        // FIRST: the initial sort's last pass wrote L[slot] for every slot: that is the symbol in front of the suffix standing there
-        const uint8_t *src = FIRST ? bc.bwt : bc.sym_in;
+        const uint8_t *src = bc.sym_in;
         if (a0 + RR_IPT <= count && ((reinterpret_cast<uintptr_t>(src) + a0) & 7) == 0) {
             sym8 = *reinterpret_cast<const uint64_t *>(src + a0);
         } else {
@@ -384,14 +375,9 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint8_t *__rest
         const uint4 *pi = reinterpret_cast<const uint4 *>(s_idx + tid * RR_IPT);
         const uint4 i0 = pi[0], i1 = pi[1];
         my_idx[0] = i0.x; my_idx[1] = i0.y; my_idx[2] = i0.z; my_idx[3] = i0.w; my_idx[4] = i1.x; my_idx[5] = i1.y; my_idx[6] = i1.z; my_idx[7] = i1.w;
-        if (FIRST) {
-#pragma unroll
-            for (int j = 0; j < RR_IPT; ++j) my_pos[j] = static_cast<uint32_t>(a0) + j;  // slot a sits at SA position a
-        } else {
-            const uint4 *pp = reinterpret_cast<const uint4 *>(s_pos + tid * RR_IPT);
-            const uint4 p0 = pp[0], p1 = pp[1];
-            my_pos[0] = p0.x; my_pos[1] = p0.y; my_pos[2] = p0.z; my_pos[3] = p0.w; my_pos[4] = p1.x; my_pos[5] = p1.y; my_pos[6] = p1.z; my_pos[7] = p1.w;
-        }
+        const uint4 *pp = reinterpret_cast<const uint4 *>(s_pos + tid * RR_IPT);
+        const uint4 p0 = pp[0], p1 = pp[1];
+        my_pos[0] = p0.x; my_pos[1] = p0.y; my_pos[2] = p0.z; my_pos[3] = p0.w; my_pos[4] = p1.x; my_pos[5] = p1.y; my_pos[6] = p1.z; my_pos[7] = p1.w;
     }
     __syncthreads();              // every thread holds its slice of s_idx in registers:
     uint32_t *s_ogid = s_idx;     // the array now collects the compacted group ids
@@ -404,15 +390,13 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint8_t *__rest
         const uint32_t suffix = my_idx[j];
         // SA position of the group's head: the head slot is in this tile (LDS) or in an earlier one (global, rare)
         const size_t hs = el >> 1;
-        const uint32_t head_pos = FIRST ? static_cast<uint32_t>(hs) : (hs >= b0 ? s_pos[hs - b0] : pos_in[hs]);
+        const uint32_t head_pos = hs >= b0 ? s_pos[hs - b0] : pos_in[hs];
         if (rank && !(el & 1u)) rank[suffix] = head_pos;  // members of a group that kept its head keep their rank: no scatter
-        if (!(f & F_SURV)) {
-            if (!FIRST) {  // the group is a singleton: this suffix is in its final place (FIRST: it already stands there, see above)
-                sa[my_pos[j]] = suffix;
-                if (bc.bwt) {
-                    bc.bwt[my_pos[j]] = static_cast<uint8_t>(sym8 >> (8 * j));
-                    if (suffix == 0) *bc.origin = my_pos[j];
-                }
+        if (!(f & F_SURV)) {  // the group is a singleton: this suffix is in its final place
+            sa[my_pos[j]] = suffix;
+            if (bc.bwt) {
+                bc.bwt[my_pos[j]] = static_cast<uint8_t>(sym8 >> (8 * j));
+                if (suffix == 0) *bc.origin = my_pos[j];
             }
         } else {
             if (f & F_HEAD) { gstart[eh] = base.surv + es; ++eh; }  // first slot of the surviving group in the new active list
@@ -429,6 +413,99 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint8_t *__rest
         out_pos[base.surv + o] = s_opos[o];
         out_gid[base.surv + o] = s_ogid[o];
         if (bc.bwt) bc.sym_out[base.surv + o] = s_osym[o];
+    }
+}
+
+// The first rerank, straight after the initial sort: slot a IS SA position a, and the sort's last pass left every suffix at its slot
+// (and its symbol in L) -- finals need no store, only the survivors are compacted into the active list; no rank array exists yet.
+// A workgroup takes up to RA_FIRST_TILES consecutive tiles (the host aims at about 8192 workgroups) and first looks up, one thread per
+// tile, which of them hold a survivor at all: 2^30 random bytes are 524 288 tiles, nearly all of them without one (a workgroup each was
+// 1.7 ms of dispatch and two dependent loads).  Every thread loads its own eight consecutive slots with 16-byte loads (no staging
+// through LDS), and the loads of the next tile with survivors are in flight while the current one is scanned and compacted.
+constexpr int RA_FIRST_TILES = 64;
+constexpr int RA_SPARSE = 64;  // survivors per tile up to which the tile's suffixes are fetched one by one
+struct RerankSlice { uint64_t fl, sym8; uint4 i0, i1; };
+__global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply_first(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ idx, size_t count,
+                                                                  const RerankAgg *__restrict__ agg, uint32_t *__restrict__ out_idx,
+                                                                  uint32_t *__restrict__ out_pos, uint32_t *__restrict__ out_gid,
+                                                                  uint32_t *__restrict__ gstart, const uint32_t *__restrict__ mail, BwtCarry bc,
+                                                                  uint32_t ntiles, uint32_t tiles_per_wg) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_out[3 * RR_TILE];  // compacted idx | pos | gid
+    __shared__ __attribute__((aligned(8))) uint8_t s_osym[RR_TILE];        // compacted symbols
+    __shared__ uint32_t s_tmp[RR_WAVES + 1];
+    __shared__ RerankAgg s_agg[RA_FIRST_TILES + 1];
+    const int tid = threadIdx.x;
+    const uint32_t tile_first = blockIdx.x * tiles_per_wg;
+    const uint32_t tile_end = tile_first + tiles_per_wg < ntiles ? tile_first + tiles_per_wg : ntiles;
+    if (static_cast<uint32_t>(tid) <= tiles_per_wg)  // the aggregates in front of each of this workgroup's tiles (and of the one behind them)
+        s_agg[tid] = tile_first + tid < ntiles ? agg[tile_first + tid] : RerankAgg{mail[0], 0, 0, 0};
+    __syncthreads();
+    auto next_with_survivors = [&](uint32_t t) {
+        while (t < tile_end && s_agg[t - tile_first].surv == s_agg[t - tile_first + 1].surv) ++t;
+        return t;
+    };
+    // a tile with few survivors (random bytes: two in 2048 slots) fetches suffix and symbol for those alone: one flag byte per slot is all
+    // the rest of it costs
+    auto sparse = [&](uint32_t t) { return s_agg[t - tile_first + 1].surv - s_agg[t - tile_first].surv <= static_cast<uint32_t>(RA_SPARSE); };
+    auto load_slice = [&](uint32_t t, RerankSlice &r) {
+        const size_t a0 = static_cast<size_t>(t) * RR_TILE + static_cast<size_t>(tid) * RR_IPT;
+        r.fl = *reinterpret_cast<const uint64_t *>(flags + a0);  // whole tiles are stored: zero past `count`
+        r.sym8 = 0;
+        if (sparse(t)) return;
+        if (a0 + RR_IPT <= count && (reinterpret_cast<uintptr_t>(idx) & 15) == 0 && (reinterpret_cast<uintptr_t>(bc.bwt) & 7) == 0) {
+            r.i0 = *reinterpret_cast<const uint4 *>(idx + a0);
+            r.i1 = *reinterpret_cast<const uint4 *>(idx + a0 + 4);
+            if (bc.bwt) r.sym8 = *reinterpret_cast<const uint64_t *>(bc.bwt + a0);  // L[slot] = the symbol in front of the suffix standing there
+        } else {
+            uint32_t v[RR_IPT];
+            for (int j = 0; j < RR_IPT; ++j) {
+                v[j] = a0 + j < count ? idx[a0 + j] : 0u;
+                if (bc.bwt && a0 + j < count) r.sym8 |= static_cast<uint64_t>(bc.bwt[a0 + j]) << (8 * j);
+            }
+            r.i0 = make_uint4(v[0], v[1], v[2], v[3]);
+            r.i1 = make_uint4(v[4], v[5], v[6], v[7]);
+        }
+    };
+    uint32_t tile = next_with_survivors(tile_first);
+    if (tile >= tile_end) return;
+    RerankSlice cur, nxt;
+    load_slice(tile, cur);
+    uint32_t *s_oidx = s_out, *s_opos = s_out + RR_TILE, *s_ogid = s_out + 2 * RR_TILE;
+    for (;;) {
+        const uint32_t tile_next = next_with_survivors(tile + 1);
+        if (tile_next < tile_end) load_slice(tile_next, nxt);
+        const size_t a0 = static_cast<size_t>(tile) * RR_TILE + static_cast<size_t>(tid) * RR_IPT;
+        uint32_t ns, nh, lh;
+        thread_summary(cur.fl, a0, ns, nh, lh);
+        const RerankAgg base = s_agg[tile - tile_first];
+        uint32_t block_surv;
+        uint32_t es = block_excl_sum<RR_WAVES>(ns, s_tmp, &block_surv);  // tile-local compaction offset
+        uint32_t eh = base.heads + block_excl_sum<RR_WAVES>(nh, s_tmp, nullptr);
+        const uint32_t my_idx[RR_IPT] = {cur.i0.x, cur.i0.y, cur.i0.z, cur.i0.w, cur.i1.x, cur.i1.y, cur.i1.z, cur.i1.w};
+        const bool few = sparse(tile);
+#pragma unroll
+        for (int j = 0; j < RR_IPT; ++j) {
+            const uint32_t f = static_cast<uint32_t>(cur.fl >> (8 * j)) & 0xFFu;  // (zero past `count`)
+            if (f & F_SURV) {
+                if (f & F_HEAD) { gstart[eh] = base.surv + es; ++eh; }  // first slot of the surviving group in the new active list
+                s_oidx[es] = few ? idx[a0 + j] : my_idx[j];
+                s_opos[es] = static_cast<uint32_t>(a0) + j;  // slot a sits at SA position a
+                s_ogid[es] = eh - 1;
+                if (bc.bwt) s_osym[es] = few ? bc.bwt[a0 + j] : static_cast<uint8_t>(cur.sym8 >> (8 * j));
+                ++es;
+            }
+        }
+        __syncthreads();
+        for (uint32_t o = tid; o < block_surv; o += RR_BLOCK) {
+            out_idx[base.surv + o] = s_oidx[o];
+            out_pos[base.surv + o] = s_opos[o];
+            out_gid[base.surv + o] = s_ogid[o];
+            if (bc.bwt) bc.sym_out[base.surv + o] = s_osym[o];
+        }
+        if (tile_next >= tile_end) break;
+        __syncthreads();  // the next tile reuses the staging arrays
+        cur = nxt;
+        tile = tile_next;
     }
 }
 
@@ -461,10 +538,14 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
     {
         // flags 1 + suffix 4 (+ position 4) + symbol 1 in; SA 4 + L 1 for finals or 13 compacted out (FIRST: finals already stand in SA / L)
         LaunchScope ls(ctx, K_RERANK_APPLY, (pos_in ? 10.0 + 9.0 : 6.0 + 13.0) * count);
-        if (pos_in)
-            k_rerank_apply<false><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(flags, idx, pos_in, count, agg, rank, sa, out_idx, out_pos, out_gid, gstart, ctx->d_mail, fb);
-        else
-            k_rerank_apply<true><<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(flags, idx, pos_in, count, agg, rank, sa, out_idx, out_pos, out_gid, gstart, ctx->d_mail, fb);
+        if (pos_in) {
+            k_rerank_apply<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(flags, idx, pos_in, count, agg, rank, sa, out_idx, out_pos, out_gid, gstart, fb);
+        } else {
+            if (rank) return ctx->fail(DK_E_INTERNAL, "rerank: the first rerank writes no ranks");
+            const uint32_t per_wg = static_cast<uint32_t>(std::min<size_t>(std::max<size_t>(ntiles / 8192, 1), RA_FIRST_TILES));
+            k_rerank_apply_first<<<dim3(div_up(ntiles, per_wg)), dim3(RR_BLOCK), 0, st>>>(flags, idx, count, agg, out_idx, out_pos, out_gid, gstart, ctx->d_mail, fb,
+                                                                                          static_cast<uint32_t>(ntiles), per_wg);
+        }
     }
     DK_HIP(ctx, hipGetLastError());
     ctx->ws_release(mark);
