@@ -153,7 +153,14 @@ struct TextKeys { const uint8_t *t = nullptr; size_t n = 0; const uint8_t *code 
 // every suffix at its slot) instead of the ping-pong buffer, and -- when bwt is given -- L[slot] = inv_code[low byte of the key] (the
 // symbol in front of the suffix rides in the key's low byte) and *origin = the slot of value 0.  A later stage overwrites the entries of
 // suffixes that are not final yet.
-struct SortFinalOut { uint32_t *vals = nullptr; uint8_t *bwt = nullptr; const uint8_t *inv_code = nullptr; uint32_t *origin = nullptr; };
+// narrow_shift >= 0 (sorts of at most 40 bits = five passes): the sorted keys are only ever compared with their neighbours afterwards, so
+// the last pass writes them as 32-bit words, (key >> narrow_shift) cut to 32 bits, into the key buffer it would have written (viewed as
+// u32) -- half the bytes to write and to read back.  What a fifth pass sorts by is exactly the bits cut off: two neighbours can differ in
+// them only where its digit changes, and those 256 places go to bucket_starts (global index of the first pair of every digit).
+struct SortFinalOut {
+    uint32_t *vals = nullptr; uint8_t *bwt = nullptr; const uint8_t *inv_code = nullptr; uint32_t *origin = nullptr;
+    int narrow_shift = -1; uint32_t *bucket_starts = nullptr;
+};
 // final_out (may be null; only with the sort of more than 8192 pairs): see SortFinalOut; then `vals` / `vals_alt` are both free on return
 int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
                int begin_bit, int end_bit, const TextKeys *text = nullptr, const SortFinalOut *final_out = nullptr);

@@ -439,7 +439,8 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))
         const uint64_t kk = s_keys[p];
         gi[k] = s_gbase[digit_of(kk, shift)] + p;
         if (p < valid) {
-            kout[gi[k]] = kk;
+            if (fin.narrow_shift >= 0) reinterpret_cast<uint32_t *>(kout)[gi[k]] = static_cast<uint32_t>(kk >> fin.narrow_shift);  // SortFinalOut
+            else kout[gi[k]] = kk;
             if (next_digit) next_digit[gi[k]] = static_cast<uint8_t>(digit_of(kk, shift + 8));  // what the next pass's histogram reads
             if (fin.bwt) fin.bwt[gi[k]] = fin.inv_code[kk & 0xFFu];  // last pass of the suffix sort's initial sort: L rides in the key's low byte
         }
@@ -604,8 +605,10 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
             LaunchScope ls(ctx, K_RADIX_SCAN, 2.0 * 1024.0 * cp.nchunks);
             k_radix_scan<<<dim3(256), dim3(64), 0, st>>>(chunk_sum, cp.nchunks, totals);
         }
+        if (fin.bucket_starts)  // the first chunk's row: pairs with a smaller digit = where every digit's pairs start
+            DK_HIP(ctx, hipMemcpyAsync(fin.bucket_starts, chunk_sum, 256 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
         {
-            LaunchScope ls(ctx, tk ? K_RADIX_SCATTER_TEXT : K_RADIX_SCATTER, ((tk ? 13.0 : 24.0) + (emit ? 1.0 : 0.0) + (fin.bwt ? 1.0 : 0.0)) * count);
+            LaunchScope ls(ctx, tk ? K_RADIX_SCATTER_TEXT : K_RADIX_SCATTER, ((tk ? 13.0 : 24.0) + (emit ? 1.0 : 0.0) + (fin.bwt ? 1.0 : 0.0) - (fin.narrow_shift >= 0 ? 4.0 : 0.0)) * count);
             const bool xcd = DK_KNOB("DK_XCD", 1) != 0;
             const size_t grid = xcd ? 8 * div_up(ntiles, 8) : ntiles;
             if (tk)
@@ -630,6 +633,8 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
 int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
                int begin_bit, int end_bit, const TextKeys *text, const SortFinalOut *final_out) {
     if (final_out && !text) return ctx->fail(DK_E_INTERNAL, "sort_pairs: a final destination only with the text pass");
+    if (final_out && final_out->narrow_shift >= 0 && (end_bit - begin_bit > 40 || !final_out->bucket_starts))
+        return ctx->fail(DK_E_INTERNAL, "sort_pairs: narrow keys need a sort of at most five passes and a place for the bucket starts");
     if (text && begin_bit != (text->with_prev ? 8 : 0)) return ctx->fail(DK_E_INTERNAL, "sort_pairs: the text pass sorts from the key's first sorted bit");
     if (count > 0xFFFFFFFEull) return ctx->fail(DK_E_ARG, "sort_pairs: count too large");
     if (text && (count != text->n || end_bit <= begin_bit)) return ctx->fail(DK_E_INTERNAL, "sort_pairs: text pass needs at least one digit");

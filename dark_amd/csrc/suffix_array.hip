@@ -143,40 +143,6 @@ struct RerankAgg { uint32_t surv, heads, last_head, pad; };
 // so a round's key need not repeat the group id above its secondary key.
 constexpr uint32_t F_HEAD = 1, F_SURV = 2, F_OLDH = 4;
 
-__device__ __forceinline__ uint32_t slot_flag_bits(uint64_t prev, uint64_t cur, uint64_t next, size_t a, size_t count,
-                                                   const uint32_t *__restrict__ gid_in) {
-    if (a >= count) return 0;
-    bool old_here = a == 0, old_next = a + 1 >= count;
-    if (gid_in) {
-        const uint32_t g = gid_in[a];
-        old_here = old_here || gid_in[a - 1] != g;
-        old_next = old_next || gid_in[a + 1] != g;
-    }
-    const bool head = old_here || cur != prev;
-    const bool next_head = old_next || next != cur;
-    const bool oldh = head && gid_in && old_here;
-    return (head ? F_HEAD : 0u) | (!(head && next_head) ? F_SURV : 0u) | (oldh ? F_OLDH : 0u);
-}
-
-// stage keys[b0-1 .. b0+RR_TILE] into s_key[0 .. RR_TILE+1] (coalesced), then the flag bytes of the tile into s_flag
-// cmp_shift: low bits of the keys that take no part in the comparison (the byte that carries the symbol in front of the suffix)
-__device__ __forceinline__ void stage_flags(const uint64_t *__restrict__ keys, size_t count, size_t b0, const uint32_t *__restrict__ gid_in,
-                                            uint64_t *s_key, uint8_t *s_flag, int cmp_shift = 0) {
-    const int tid = threadIdx.x;
-    for (int o = tid; o < RR_TILE + 2; o += RR_BLOCK) {
-        const size_t a = b0 + o;  // slot a - 1
-        const uint64_t k = (a >= 1 && a - 1 < count) ? keys[a - 1] : 0;
-        s_key[o] = k >> cmp_shift;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < RR_IPT; ++k) {
-        const int o = k * RR_BLOCK + tid;
-        s_flag[o] = static_cast<uint8_t>(slot_flag_bits(s_key[o], s_key[o + 1], s_key[o + 2], b0 + o, count, gid_in));
-    }
-    __syncthreads();
-}
-
 // the RR_IPT consecutive slots of this thread: counts and the last head, encoded (slot << 1) | old_head so that one
 // max-scan carries both
 __device__ __forceinline__ void thread_summary(uint64_t fl, size_t a0, uint32_t &ns, uint32_t &nh, uint32_t &lh) {
@@ -190,34 +156,125 @@ __device__ __forceinline__ void thread_summary(uint64_t fl, size_t a0, uint32_t 
     }
 }
 
-// flags_out: one flag byte per slot (whole tiles: the array holds ntiles * RR_TILE bytes, slots past `count` get 0) -- the apply phase reads
-// these instead of the keys and group ids (8 + 4 bytes per slot) it would need to work the flags out again
-__global__ __launch_bounds__(RR_BLOCK) void k_rerank_reduce(const uint64_t *__restrict__ keys, size_t count, const uint32_t *__restrict__ gid_in,
-                                                             RerankAgg *__restrict__ agg, int cmp_shift, uint8_t *__restrict__ flags_out) {
-    __shared__ uint64_t s_key[RR_TILE + 2];
-    __shared__ __attribute__((aligned(8))) uint8_t s_flag[RR_TILE];
-    __shared__ uint32_t s_red[3][RR_WAVES];
-    const size_t b0 = static_cast<size_t>(blockIdx.x) * RR_TILE;
-    stage_flags(keys, count, b0, gid_in, s_key, s_flag, cmp_shift);
-    const size_t a0 = b0 + static_cast<size_t>(threadIdx.x) * RR_IPT;
-    const uint64_t fl8 = *reinterpret_cast<const uint64_t *>(s_flag + threadIdx.x * RR_IPT);
-    *reinterpret_cast<uint64_t *>(flags_out + a0) = fl8;
-    uint32_t ns, nh, lh;
-    thread_summary(fl8, a0, ns, nh, lh);
-    ns = wave_sum(ns);
-    nh = wave_sum(nh);
-    lh = wave_max(lh);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { s_red[0][wave] = ns; s_red[1][wave] = nh; s_red[2][wave] = lh; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        RerankAgg r{0, 0, 0, 0};
-        for (int w = 0; w < RR_WAVES; ++w) {
-            r.surv += s_red[0][w];
-            r.heads += s_red[1][w];
-            r.last_head = r.last_head > s_red[2][w] ? r.last_head : s_red[2][w];
+// k_rerank_reduce: the flag byte of every slot (flags_out: whole tiles, the array holds ntiles * RR_TILE bytes, slots past `count` get 0 --
+// the apply phase reads these instead of the keys and group ids it would need to work the flags out again) and the aggregates of every
+// tile of RR_TILE slots.  A thread owns RR_IPT consecutive slots: their keys, the one before and the one after arrive in registers
+// with 16-byte loads (no staging through LDS), the flags never leave the registers.  A workgroup takes tiles_per_wg consecutive tiles
+// (524 288 workgroups of one tile each were dispatch-bound at 2^30 slots: 2.1 ms whether the keys had 8 bytes or 4), the loads of the
+// next tile in flight while the current one is reduced.
+// cmp_shift: low bits of the keys that take no part in the comparison (the byte that carries the symbol in front of the suffix).
+// K = uint32_t: the first rerank after a sort that left NARROW keys (SortFinalOut::narrow_shift: 32-bit words, at most five passes).
+// The bits a fifth pass sorted by are not in the words: a slot where that pass's digit changes (bucket_starts: 256 places in the whole
+// array, those inside the workgroup's stretch are collected once) is a head whatever its word says.  No old groups at that stage.
+template <typename K>
+struct ReduceSlice { K k[RR_IPT + 2]; uint32_t g[RR_IPT + 2]; };
+
+template <typename K>
+__global__ __launch_bounds__(RR_BLOCK) void k_rerank_reduce(const K *__restrict__ keys, size_t count, const uint32_t *__restrict__ gid_in,
+                                                             RerankAgg *__restrict__ agg, int cmp_shift, uint8_t *__restrict__ flags_out,
+                                                             const uint32_t *__restrict__ bucket_starts, uint32_t ntiles, uint32_t tiles_per_wg) {
+    constexpr bool NARROW = sizeof(K) == 4;
+    __shared__ uint32_t s_red[2][3][RR_WAVES];
+    __shared__ uint32_t s_forced[NARROW ? 256 : 1];
+    __shared__ uint32_t s_nforced;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t t0 = blockIdx.x * tiles_per_wg;
+    const uint32_t t1 = t0 + tiles_per_wg < ntiles ? t0 + tiles_per_wg : ntiles;
+    if (NARROW) {
+        static_assert(RR_BLOCK == 256, "one thread per bucket");
+        if (tid == 0) s_nforced = 0;
+        __syncthreads();
+        const uint64_t s = bucket_starts[tid];
+        if (s >= static_cast<uint64_t>(t0) * RR_TILE && s <= static_cast<uint64_t>(t1) * RR_TILE) s_forced[atomicAdd(&s_nforced, 1u)] = static_cast<uint32_t>(s);
+        __syncthreads();
+    }
+    auto load_slice = [&](uint32_t tile, ReduceSlice<K> &r) {
+        const size_t a0 = static_cast<size_t>(tile) * RR_TILE + static_cast<size_t>(tid) * RR_IPT;
+        if (a0 >= 1 && a0 + RR_IPT + 1 <= count && (reinterpret_cast<uintptr_t>(keys) & 15) == 0 && (reinterpret_cast<uintptr_t>(gid_in) & 15) == 0) {
+            constexpr int PER = 16 / sizeof(K);  // keys per 16-byte load
+            const uint4 *p = reinterpret_cast<const uint4 *>(keys + a0);
+#pragma unroll
+            for (int q = 0; q < RR_IPT / PER; ++q) {
+                const uint4 v = p[q];
+                if (NARROW) {
+                    r.k[1 + 4 * q] = static_cast<K>(v.x); r.k[2 + 4 * q] = static_cast<K>(v.y); r.k[3 + 4 * q] = static_cast<K>(v.z); r.k[4 + 4 * q] = static_cast<K>(v.w);
+                } else {
+                    r.k[1 + 2 * q] = static_cast<K>((static_cast<uint64_t>(v.y) << 32) | v.x);
+                    r.k[2 + 2 * q] = static_cast<K>((static_cast<uint64_t>(v.w) << 32) | v.z);
+                }
+            }
+            r.k[0] = keys[a0 - 1];
+            r.k[RR_IPT + 1] = keys[a0 + RR_IPT];
+            if (gid_in) {
+                const uint4 g0 = *reinterpret_cast<const uint4 *>(gid_in + a0), g1 = *reinterpret_cast<const uint4 *>(gid_in + a0 + 4);
+                r.g[1] = g0.x; r.g[2] = g0.y; r.g[3] = g0.z; r.g[4] = g0.w; r.g[5] = g1.x; r.g[6] = g1.y; r.g[7] = g1.z; r.g[8] = g1.w;
+                r.g[0] = gid_in[a0 - 1];
+                r.g[RR_IPT + 1] = gid_in[a0 + RR_IPT];
+            }
+        } else {  // the array's ends
+#pragma unroll
+            for (int j = 0; j < RR_IPT + 2; ++j) {
+                const size_t a = a0 + j;  // slot a - 1
+                const bool in = a >= 1 && a - 1 < count;
+                r.k[j] = in ? keys[a - 1] : K(0);
+                r.g[j] = in && gid_in ? gid_in[a - 1] : 0u;
+            }
         }
-        agg[blockIdx.x] = r;
+    };
+    static_assert(RR_IPT == 8, "two 16-byte loads of group ids per thread");
+    if (t0 >= t1) return;
+    ReduceSlice<K> cur, nxt;
+    load_slice(t0, cur);
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+        if (tile + 1 < t1) load_slice(tile + 1, nxt);
+        const size_t a0 = static_cast<size_t>(tile) * RR_TILE + static_cast<size_t>(tid) * RR_IPT;
+        uint32_t forced = 0;  // bit j: slot a0 + j - 1 starts a bucket (j = 0 .. RR_IPT + 1)
+        if (NARROW) {
+            const uint32_t nf = s_nforced;
+            for (uint32_t i = 0; i < nf; ++i) {
+                const uint64_t rel = static_cast<uint64_t>(s_forced[i]) + 1 - a0;  // (mod 2^64: far off when the start lies before the slice)
+                if (rel < RR_IPT + 2) forced |= 1u << rel;
+            }
+        }
+        uint64_t fl8 = 0;
+#pragma unroll
+        for (int j = 0; j < RR_IPT; ++j) {
+            const size_t a = a0 + j;
+            if (a >= count) break;
+            const K prev = NARROW ? cur.k[j] : static_cast<K>(cur.k[j] >> cmp_shift), here = NARROW ? cur.k[j + 1] : static_cast<K>(cur.k[j + 1] >> cmp_shift),
+                    next = NARROW ? cur.k[j + 2] : static_cast<K>(cur.k[j + 2] >> cmp_shift);
+            // The keys of one old group are compared among themselves only: across a group boundary a new group starts whatever the keys
+            // say, so a round's key need not repeat the group id above its secondary key.
+            bool old_here = a == 0, old_next = a + 1 >= count;
+            if (gid_in) {
+                old_here = old_here || cur.g[j] != cur.g[j + 1];
+                old_next = old_next || cur.g[j + 2] != cur.g[j + 1];
+            }
+            const bool head = old_here || here != prev || ((forced >> (j + 1)) & 1u);
+            const bool next_head = old_next || next != here || ((forced >> (j + 2)) & 1u);
+            const bool oldh = head && gid_in && old_here;
+            const uint32_t f = (head ? F_HEAD : 0u) | (!(head && next_head) ? F_SURV : 0u) | (oldh ? F_OLDH : 0u);
+            fl8 |= static_cast<uint64_t>(f) << (8 * j);
+        }
+        *reinterpret_cast<uint64_t *>(flags_out + a0) = fl8;
+        uint32_t ns, nh, lh;
+        thread_summary(fl8, a0, ns, nh, lh);
+        ns = wave_sum(ns);
+        nh = wave_sum(nh);
+        lh = wave_max(lh);
+        uint32_t (*red)[RR_WAVES] = s_red[tile & 1u];  // two sets: a set is written again two tiles later, behind the barrier of the tile between
+        if (lane == 0) { red[0][wave] = ns; red[1][wave] = nh; red[2][wave] = lh; }
+        __syncthreads();
+        if (tid == 0) {
+            RerankAgg r{0, 0, 0, 0};
+            for (int w = 0; w < RR_WAVES; ++w) {
+                r.surv += red[0][w];
+                r.heads += red[1][w];
+                r.last_head = r.last_head > red[2][w] ? r.last_head : red[2][w];
+            }
+            agg[tile] = r;
+        }
+        if (tile + 1 < t1) cur = nxt;
     }
 }
 
@@ -510,8 +567,10 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply_first(const uint8_t *
 }
 
 // rank == nullptr: no rank array exists yet (first rerank, text rounds)
+// narrow_starts != nullptr (first rerank only): `keys` holds 32-bit words (SortFinalOut::narrow_shift), narrow_starts the 256 bucket starts
 int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_t *pos_in, size_t count, const uint32_t *gid_in, uint32_t *rank,
-           uint32_t *sa, uint32_t *out_idx, uint32_t *out_pos, uint32_t *out_gid, uint32_t *gstart, BwtCarry fb = NO_CARRY) {
+           uint32_t *sa, uint32_t *out_idx, uint32_t *out_pos, uint32_t *out_gid, uint32_t *gstart, BwtCarry fb = NO_CARRY,
+           const uint32_t *narrow_starts = nullptr) {
     const size_t ntiles = div_up(count, RR_TILE);
     const size_t mark = ctx->ws_mark();
     RerankAgg *agg = ctx->ws_alloc<RerankAgg>(ntiles);
@@ -519,8 +578,16 @@ int rerank(dk_ctx *ctx, const uint64_t *keys, const uint32_t *idx, const uint32_
     if (!agg || !flags) return DK_E_NOMEM;
     hipStream_t st = ctx->stream;
     {
-        LaunchScope ls(ctx, K_RERANK_REDUCE, (8.0 + (gid_in ? 4.0 : 0.0) + 1.0) * count);
-        k_rerank_reduce<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(keys, count, gid_in, agg, pos_in ? 0 : fb.cmp_shift, flags);
+        LaunchScope ls(ctx, K_RERANK_REDUCE, ((narrow_starts ? 4.0 : 8.0) + (gid_in ? 4.0 : 0.0) + 1.0) * count);
+        const uint32_t per_wg = static_cast<uint32_t>(std::min<size_t>(std::max<size_t>(ntiles / 16384, 1), 64));
+        const dim3 grid(static_cast<unsigned>(div_up(ntiles, per_wg))), block(RR_BLOCK);
+        if (narrow_starts) {
+            if (pos_in || gid_in) return ctx->fail(DK_E_INTERNAL, "rerank: narrow keys only in the first rerank");
+            k_rerank_reduce<uint32_t><<<grid, block, 0, st>>>(reinterpret_cast<const uint32_t *>(keys), count, nullptr, agg, 0, flags, narrow_starts,
+                                                              static_cast<uint32_t>(ntiles), per_wg);
+        } else {
+            k_rerank_reduce<uint64_t><<<grid, block, 0, st>>>(keys, count, gid_in, agg, pos_in ? 0 : fb.cmp_shift, flags, nullptr, static_cast<uint32_t>(ntiles), per_wg);
+        }
     }
     {
         LaunchScope ls(ctx, K_RERANK_SCAN, 32.0 * ntiles);
@@ -1068,17 +1135,18 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     const bool trace = DK_KNOB("DK_TRACE", 0) != 0;
 
     // 2. how long a prefix must the initial sort cover?  DK_PREFIX: 0 = always the full key, 1 = ask the sample (default),
-    //    2 = always the shortest candidate (test hook: every input then takes the short-prefix path)
+    //    2 / 3 = always the shortest / second candidate (test hooks: every input then takes the short-prefix path; the second one is
+    //    the five-pass sort whose narrow keys need the bucket starts)
     const int prefix_mode = DK_KNOB("DK_PREFIX", 1);
     int spk_sort = spk;
-    if (prefix_mode != 0 && (n >= (1u << 22) || prefix_mode == 2)) {
+    if (prefix_mode != 0 && (n >= (1u << 22) || prefix_mode >= 2)) {
         ProbeCands cands{0, {0, 0, 0, 0}};
         for (int passes = 4; passes <= 7 && cands.count < PP_MAX_CAND; ++passes) {
             const int k = (8 * passes) / bits;
             if (k >= 1 && k < spk && (cands.count == 0 || cands.sym[cands.count - 1] != k)) cands.sym[cands.count++] = k;
         }
-        if (cands.count > 0 && prefix_mode == 2) {
-            spk_sort = cands.sym[0];
+        if (cands.count > 0 && (prefix_mode == 2 || prefix_mode == 3)) {
+            spk_sort = cands.sym[prefix_mode == 3 && cands.count > 1 ? 1 : 0];
         } else if (cands.count > 0) {
             const uint32_t m = static_cast<uint32_t>(std::min<double>(n / 2.0, 10.0 * std::sqrt(static_cast<double>(n))));
             const uint32_t span = static_cast<uint32_t>(n / m);
@@ -1128,6 +1196,8 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
         DK_HIP(ctx, hipMemcpyAsync(d_inv, ctx->h_mail + 576, 256, hipMemcpyHostToDevice, st));
     }
     const int key_shift = carry_bwt ? 8 : 0;
+    const bool narrow_keys = DK_KNOB("DK_NARROW_KEYS", 1) != 0 && bits * spk_sort <= 40;
+    uint32_t *d_starts = ctx->d_mail + 720;  // 256 words
 
     // 3. initial sort; its first pass builds the keys from the text (no key array is ever written unsorted)
     {
@@ -1138,6 +1208,8 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
         SortFinalOut fin;
         fin.vals = d_sa;
         if (carry_bwt) { fin.bwt = d_bwt; fin.inv_code = d_inv; fin.origin = d_origin; }
+        // up to 40 sorted bits (short prefixes: random bytes, small alphabets): the last pass leaves 32-bit keys for the first rerank
+        if (narrow_keys) { fin.narrow_shift = key_shift; fin.bucket_starts = d_starts; }
         DK_TRY(sort_pairs(ctx, keys, keys_alt, vals, vals_alt, n, key_shift, bits * spk_sort + key_shift, &tk, &fin));
     }
 
@@ -1147,7 +1219,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     size_t active = 0, groups = 0, nbig = 0, nmedium = 0, nbiggroups = 0;
     bool have_ranks = false;
     const BwtCarry first_bc{key_shift, carry_bwt ? d_bwt : nullptr, d_inv, d_origin, nullptr, sym};
-    DK_TRY(rerank(ctx, keys, d_sa, nullptr, n, nullptr, nullptr, d_sa, vals_alt, pos, gid, gstart, first_bc));
+    DK_TRY(rerank(ctx, keys, d_sa, nullptr, n, nullptr, nullptr, d_sa, vals_alt, pos, gid, gstart, first_bc, narrow_keys ? d_starts : nullptr));
     DK_TRY(classify_and_read(ctx, n / 2, gstart, bigidx, bigoff, &active, &groups, &nbig, &nmedium, &nbiggroups));
     std::swap(vals, vals_alt);  // vals = suffix indices of the active list
 

@@ -4,7 +4,7 @@ the same bytes.
 The device-side switches exist in the TUNING build only (dark_amd/libdark_amd_tuning.so, -DDK_TUNING: csrc/context.hpp DK_KNOB); the
 product library has them compiled in as constants:
   DK_XCD=0 plain tile order | DK_DIGIT_PLANE=1 histograms from the digit plane at every size | DK_PLATEAU=0 general doubling rounds only
-  DK_BWT_CARRY=0 L gathered from the suffix array instead of riding with the suffixes | DK_PREFIX=0|1|2 prefix length of the initial sort"""
+  DK_BWT_CARRY=0 L gathered from the suffix array instead of riding with the suffixes | DK_PREFIX=0|1|2|3 prefix length of the initial sort"""
 import os
 import subprocess
 import sys
@@ -79,7 +79,7 @@ print("ok")
 """
 
 
-# the short-prefix path of the suffix sort (DK_PREFIX: 0 = never, 1 = ask the sample, 2 = always): initial sort on a few leading
+# the short-prefix path of the suffix sort (DK_PREFIX: 0 = never, 1 = ask the sample, 2 / 3 = always, four / five passes): initial sort on a few leading
 # symbols, survivors finished from the text, rank array built late only when long repeats remain
 PREFIX_SNIPPET = r"""
 import os, sys, numpy as np
@@ -103,7 +103,7 @@ cases = [
     ("zero-heavy", np.where(rng.random(4_300_000) < 0.9, 0, rng.integers(0, 7, size=4_300_000)).astype(np.uint8)),
     ("ends in zeros", np.concatenate([rng.integers(0, 256, size=4_200_000, dtype=np.uint8), np.zeros(3000, np.uint8)])),
 ]
-if os.environ.get("DK_PREFIX") == "2":
+if os.environ.get("DK_PREFIX") in ("2", "3"):
     cases += [("text", datagen.wiki_like(3_000_000, 9)), ("ab", np.frombuffer(b"ab" * 40000, np.uint8)),
               ("one", np.array([7], np.uint8)), ("two", np.array([1, 1], np.uint8)), ("tiny", rng.integers(0, 3, size=70, dtype=np.uint8)),
               ("run then one", np.concatenate([np.zeros(100000, np.uint8), np.ones(1, np.uint8)])),
@@ -153,6 +153,6 @@ def test_gpu_variants_match_oracle(env):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["0", "1", "2"])
+@pytest.mark.parametrize("mode", ["0", "1", "2", "3"])
 def test_gpu_prefix_paths_match_oracle(mode):
     _run(PREFIX_SNIPPET, {"DK_PREFIX": mode, "DK_TRACE": "1"}, tuning=True)
