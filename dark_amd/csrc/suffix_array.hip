@@ -832,11 +832,27 @@ __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__rest
     const size_t b0 = static_cast<size_t>(blockIdx.x) * LS_TILE;
     uint32_t my_idx[LS_IPT];
     R2 my_r2[LS_IPT];
+    // everything a slot needs from global memory is asked for up front (suffix, group and its extent, symbol in front): the loop after
+    // the barrier then runs on registers and LDS alone -- a load there would wait behind the stores of the slots before it
+    uint32_t my_gs[LS_IPT], my_ge[LS_IPT];
+    uint8_t my_sym[LS_IPT];
+#pragma unroll
+    for (int k = 0; k < LS_IPT; ++k) {
+        const size_t a = b0 + static_cast<size_t>(k) * LS_BLOCK + tid;
+        my_gs[k] = my_ge[k] = 0;
+        my_sym[k] = 0;
+        if (a < count) {
+            my_idx[k] = act_idx[a];
+            const uint32_t g = act_gid[a];
+            my_gs[k] = gstart[g];
+            my_ge[k] = gstart[g + 1];
+            if (sym_in) my_sym[k] = sym_in[a];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < LS_IPT; ++k) {
         const size_t a = b0 + static_cast<size_t>(k) * LS_BLOCK + tid;
         if (a < count) {
-            my_idx[k] = act_idx[a];
             my_r2[k] = second(my_idx[k]);
             s_r2[LS_MAX + k * LS_BLOCK + tid] = my_r2[k];
         }
@@ -864,8 +880,7 @@ __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__rest
     for (int k = 0; k < LS_IPT; ++k) {
         const size_t a = b0 + static_cast<size_t>(k) * LS_BLOCK + tid;
         if (a >= count) continue;
-        const uint32_t g = act_gid[a];
-        const uint32_t gs = gstart[g], ge = gstart[g + 1];
+        const uint32_t gs = my_gs[k], ge = my_ge[k];
         if (ge - gs <= static_cast<uint32_t>(LS_MAX)) {
             const R2 mine = my_r2[k];
             // LDS index of slot b is b - (b0 - LS_MAX) = b + LS_MAX - b0 (never negative: gs >= a - LS_MAX + 1)
@@ -877,9 +892,9 @@ __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__rest
             }
             key_out[gs + before] = static_cast<uint64_t>(mine);
             idx_out[gs + before] = my_idx[k];
-            if (sym_in) sym_out[gs + before] = sym_in[a];  // the symbol in front of the suffix travels with it (BwtCarry)
+            if (sym_in) sym_out[gs + before] = my_sym[k];  // the symbol in front of the suffix travels with it (BwtCarry)
         } else {
-            const uint32_t bj = bigidx[g];
+            const uint32_t bj = bigidx[act_gid[a]];
             const uint32_t bo = bigoff[bj] + (static_cast<uint32_t>(a) - gs);
             bkeys[bo] = (static_cast<uint64_t>(bj) << kb) | (static_cast<uint64_t>(my_r2[k]) >> (kbits - kb));
             bidx[bo] = my_idx[k];
@@ -941,11 +956,17 @@ __global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__res
     if (prev_live && *prev_live == 0) return;
     const int tid = threadIdx.x;
     const size_t b0 = static_cast<size_t>(blockIdx.x) * LS_TILE;
-    uint32_t my_idx[LS_IPT], my_r2[LS_IPT];
+    uint32_t my_idx[LS_IPT], my_r2[LS_IPT], my_meta[LS_IPT];
+    uint8_t my_sym[LS_IPT];
 #pragma unroll
-    for (int k = 0; k < LS_IPT; ++k) {
+    for (int k = 0; k < LS_IPT; ++k) {  // (all the loads of a slot up front: see k_round_local)
         const size_t a = b0 + static_cast<size_t>(k) * LS_BLOCK + tid;
         my_idx[k] = a < slots ? idx_in[a] : PL_DEAD;
+        my_meta[k] = (my_idx[k] & PL_DEAD_BIT) ? 0u : meta_in[a];
+        my_sym[k] = (sym_in && !(my_idx[k] & PL_DEAD_BIT)) ? sym_in[a] : uint8_t(0);
+    }
+#pragma unroll
+    for (int k = 0; k < LS_IPT; ++k) {
         my_r2[k] = (my_idx[k] & PL_DEAD_BIT) ? 0u : rank2_of(rank, my_idx[k], n, h);
         s_r2[PL_MAX + k * LS_BLOCK + tid] = my_r2[k];
     }
@@ -973,7 +994,7 @@ __global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__res
         const size_t a = b0 + static_cast<size_t>(k) * LS_BLOCK + tid;
         if (a >= slots) continue;
         if (my_idx[k] & PL_DEAD_BIT) { idx_out[a] = PL_DEAD; continue; }  // a dead slot is never inside a live group's range
-        const uint32_t m = meta_in[a];
+        const uint32_t m = my_meta[k];
         const uint32_t gs = static_cast<uint32_t>(a) - (m & PL_OFF_MASK), ge = gs + ((m >> PL_BITS) & PL_OFF_MASK) + 1u;
         const uint32_t mine = my_r2[k];
         const uint32_t base = static_cast<uint32_t>(PL_MAX) - static_cast<uint32_t>(b0);  // LDS index of slot b = b + base (mod 2^32)
@@ -990,12 +1011,12 @@ __global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__res
         if (eq == 1) {  // alone in its new group: final
             const uint32_t p = pos[dest];
             sa[p] = my_idx[k];
-            if (sym_in) bwt[p] = sym_in[a];
+            if (sym_in) bwt[p] = my_sym[k];
             if (origin && my_idx[k] == 0) *origin = p;
             idx_out[dest] = my_idx[k] | PL_DEAD_BIT;  // k_plateau_ranks still needs the suffix; dead for every later round
         } else {
             idx_out[dest] = my_idx[k];
-            if (sym_in) sym_out[dest] = sym_in[a];
+            if (sym_in) sym_out[dest] = my_sym[k];
             ++alive;
         }
     }
