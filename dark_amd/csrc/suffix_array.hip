@@ -988,12 +988,16 @@ __global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__res
         }
     }
     __syncthreads();
+    // three sweeps over the thread's slots: places and new groups from LDS alone; then the SA positions of the slots that became final
+    // (one load each, all in flight together); then the stores.  A load between the stores would wait for every store before it.
     uint32_t alive = 0;
+    uint32_t dest[LS_IPT], meta_new[LS_IPT], fin_pos[LS_IPT];
 #pragma unroll
     for (int k = 0; k < LS_IPT; ++k) {
         const size_t a = b0 + static_cast<size_t>(k) * LS_BLOCK + tid;
-        if (a >= slots) continue;
-        if (my_idx[k] & PL_DEAD_BIT) { idx_out[a] = PL_DEAD; continue; }  // a dead slot is never inside a live group's range
+        dest[k] = ~0u;  // dead slot (or past the list)
+        meta_new[k] = 0;
+        if (a >= slots || (my_idx[k] & PL_DEAD_BIT)) continue;
         const uint32_t m = my_meta[k];
         const uint32_t gs = static_cast<uint32_t>(a) - (m & PL_OFF_MASK), ge = gs + ((m >> PL_BITS) & PL_OFF_MASK) + 1u;
         const uint32_t mine = my_r2[k];
@@ -1005,18 +1009,30 @@ __global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__res
             eq += v == mine;
             eq_before += (v == mine) && b < static_cast<uint32_t>(a);
         }
-        const uint32_t dest = gs + less + eq_before;
+        dest[k] = gs + less + eq_before;
         const uint32_t moved = less ? PL_MOVED : 0u;  // new head slot gs + less: the rank becomes pos[gs + less]
-        meta_out[dest] = eq_before | ((eq - 1u) << PL_BITS) | moved;
-        if (eq == 1) {  // alone in its new group: final
-            const uint32_t p = pos[dest];
+        meta_new[k] = eq_before | ((eq - 1u) << PL_BITS) | moved;
+    }
+#pragma unroll
+    for (int k = 0; k < LS_IPT; ++k) {
+        const bool final_now = dest[k] != ~0u && (meta_new[k] >> PL_BITS & PL_OFF_MASK) == 0;  // alone in its new group
+        fin_pos[k] = final_now ? pos[dest[k]] : ~0u;
+    }
+#pragma unroll
+    for (int k = 0; k < LS_IPT; ++k) {
+        const size_t a = b0 + static_cast<size_t>(k) * LS_BLOCK + tid;
+        if (a >= slots) continue;
+        if (my_idx[k] & PL_DEAD_BIT) { idx_out[a] = PL_DEAD; continue; }  // a dead slot is never inside a live group's range
+        meta_out[dest[k]] = meta_new[k];
+        if (fin_pos[k] != ~0u) {  // final
+            const uint32_t p = fin_pos[k];
             sa[p] = my_idx[k];
             if (sym_in) bwt[p] = my_sym[k];
             if (origin && my_idx[k] == 0) *origin = p;
-            idx_out[dest] = my_idx[k] | PL_DEAD_BIT;  // k_plateau_ranks still needs the suffix; dead for every later round
+            idx_out[dest[k]] = my_idx[k] | PL_DEAD_BIT;  // k_plateau_ranks still needs the suffix; dead for every later round
         } else {
-            idx_out[dest] = my_idx[k];
-            if (sym_in) sym_out[dest] = my_sym[k];
+            idx_out[dest[k]] = my_idx[k];
+            if (sym_in) sym_out[dest[k]] = my_sym[k];
             ++alive;
         }
     }
