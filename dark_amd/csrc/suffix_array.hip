@@ -809,7 +809,7 @@ template <bool TEXT>
 __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__restrict__ act_idx, const uint32_t *__restrict__ act_gid,
                                                           const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ bigidx,
                                                           const uint32_t *__restrict__ bigoff,
-                                                          const uint32_t *__restrict__ rank, uint32_t n, uint32_t h, int kbits, int kb,
+                                                          const uint32_t *__restrict__ rank, uint32_t n, uint32_t h, int kbits, int kb, int big_carry,
                                                           size_t count, uint64_t *__restrict__ key_out, uint32_t *__restrict__ idx_out,
                                                           uint64_t *__restrict__ bkeys, uint32_t *__restrict__ bidx,
                                                           uint32_t *__restrict__ bslot, TextSource ts,
@@ -896,7 +896,9 @@ __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__rest
         } else {
             const uint32_t bj = bigidx[act_gid[a]];
             const uint32_t bo = bigoff[bj] + (static_cast<uint32_t>(a) - gs);
-            bkeys[bo] = (static_cast<uint64_t>(bj) << kb) | (static_cast<uint64_t>(my_r2[k]) >> (kbits - kb));
+            const uint64_t bkey = (static_cast<uint64_t>(bj) << kb) | (static_cast<uint64_t>(my_r2[k]) >> (kbits - kb));
+            // big_carry: the symbol in front of the suffix rides below the sorted bits, like in the initial sort (BwtCarry)
+            bkeys[bo] = big_carry ? (bkey << 8) | my_sym[k] : bkey;
             bidx[bo] = my_idx[k];
             bslot[bo] = static_cast<uint32_t>(a);
         }
@@ -904,19 +906,21 @@ __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__rest
 }
 
 // sorted big list -> back into the slots of the big groups: a sorted element stays inside its group's range of the big list, and
-// position q of that list came from slot bslot[q].  sym_out (BwtCarry): the few members of big groups fetch the symbol in front of
-// their suffix from the text again instead of dragging it through the sort.
+// position q of that list came from slot bslot[q].  sym_out (BwtCarry): the symbol in front of the suffix comes back in the key's low
+// byte (big_carry: it rode below the sorted bits) -- or, when the key had no room for it, from the text again: one random byte per
+// member, which on word-like text (half of all suffixes in big groups after the initial sort) was a millisecond per 1e8 bytes.
 __global__ __launch_bounds__(256) void k_big_back(const uint64_t *__restrict__ bkeys, const uint32_t *__restrict__ bidx,
                                                    const uint32_t *__restrict__ bslot, size_t nbig, uint64_t *__restrict__ key_out,
                                                    uint32_t *__restrict__ idx_out, const uint8_t *__restrict__ text, uint32_t n,
-                                                   uint8_t *__restrict__ sym_out) {
+                                                   uint8_t *__restrict__ sym_out, int big_carry) {
     const size_t bo = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (bo >= nbig) return;
     const uint32_t a = bslot[bo];
     const uint32_t suffix = bidx[bo];
-    key_out[a] = bkeys[bo];
+    const uint64_t k = bkeys[bo];
+    key_out[a] = big_carry ? k >> 8 : k;
     idx_out[a] = suffix;
-    if (sym_out) sym_out[a] = text[suffix ? suffix - 1 : n - 1];
+    if (sym_out) sym_out[a] = big_carry ? static_cast<uint8_t>(k) : text[suffix ? suffix - 1 : n - 1];
 }
 
 // ---- plateau rounds: every group has at most PL_MAX members ---------------------------------------------------------------------
@@ -1307,25 +1311,26 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
             kbits = kb = static_cast<int>(ceil_log2_u64(static_cast<uint64_t>(n) + h_eff));
         }
         const TextSource ts{d_text, d_code, raw_text ? 0 : bits, tsym};
+        const int big_carry = carry_bwt && kb + bsbits + 8 <= 64 ? 1 : 0;  // the big list's keys have room for the symbol in front
         uint32_t *bslot = pos_alt;  // written by the rerank at the end of the round only: free until k_big_back has read it
         {
             LaunchScope ls(ctx, K_ROUND_LOCAL, 8.0 * active + 4.0 * active + 12.0 * active);
             if (tsym > 0)
                 k_round_local<true><<<dim3(div_up(active, LS_TILE)), dim3(LS_BLOCK), 0, st>>>(
-                    vals, gid, gstart, bigidx, bigoff, rank, static_cast<uint32_t>(n), h_eff, kbits, kb, active, keys, vals_alt, keys_alt, vals_3, bslot, ts, sym, sym_alt);
+                    vals, gid, gstart, bigidx, bigoff, rank, static_cast<uint32_t>(n), h_eff, kbits, kb, big_carry, active, keys, vals_alt, keys_alt, vals_3, bslot, ts, sym, sym_alt);
             else
                 k_round_local<false><<<dim3(div_up(active, LS_TILE)), dim3(LS_BLOCK), 0, st>>>(
-                    vals, gid, gstart, bigidx, bigoff, rank, static_cast<uint32_t>(n), h_eff, kbits, kb, active, keys, vals_alt, keys_alt, vals_3, bslot, ts, sym, sym_alt);
+                    vals, gid, gstart, bigidx, bigoff, rank, static_cast<uint32_t>(n), h_eff, kbits, kb, big_carry, active, keys, vals_alt, keys_alt, vals_3, bslot, ts, sym, sym_alt);
         }
         DK_HIP(ctx, hipGetLastError());
         if (nbig > 0) {
             uint64_t *bk = keys_alt, *bk_alt = keys_3;
             uint32_t *bv = vals_3, *bv_alt = vals;  // the round's input list has been read (k_round_local); the rerank rewrites it below
-            DK_TRY(sort_pairs(ctx, bk, bk_alt, bv, bv_alt, nbig, 0, kb + bsbits));
+            DK_TRY(sort_pairs(ctx, bk, bk_alt, bv, bv_alt, nbig, 8 * big_carry, kb + bsbits + 8 * big_carry));
             {
                 LaunchScope ls(ctx, K_BIG_BACK, 28.0 * nbig);
                 k_big_back<<<dim3(div_up(nbig, 256)), dim3(256), 0, st>>>(bk, bv, bslot, nbig, keys, vals_alt, d_text, static_cast<uint32_t>(n),
-                                                                          carry_bwt ? sym_alt : nullptr);
+                                                                          carry_bwt ? sym_alt : nullptr, big_carry);
             }
             DK_HIP(ctx, hipGetLastError());
         }
