@@ -165,8 +165,11 @@ struct SortFinalOut {
 int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
                int begin_bit, int end_bit, const TextKeys *text = nullptr, const SortFinalOut *final_out = nullptr);
 // scratch_b (n u64, may be null): second pair buffer of the LDS-window form (inverse of a permutation of up to 2^27 entries)
+// marked_val (may be null; only honoured by the LDS-window form, see inverse_through_windows): entries of idx with bit 31 set stand for
+// idx & 0x7FFFFFFF and take their value from marked_val[i] instead of i
 int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, size_t count, size_t limit, uint64_t *scratch,
-                         uint64_t *scratch_b, uint32_t *dst);
+                         uint64_t *scratch_b, uint32_t *dst, const uint32_t *marked_val = nullptr);
+bool inverse_through_windows(size_t n);  // does the inverse of a permutation of n entries take the LDS-window form?
 // suffix_array.hip: d_sa_out may alias nothing in the workspace; d_text is caller or ctx owned
 // d_bwt / d_origin / bwt_written (all three or none): when the sort finds the BWT on its way (short-prefix path) it writes L and the
 // origin word and sets *bwt_written; otherwise the caller gathers (bwt_forward_device does both)

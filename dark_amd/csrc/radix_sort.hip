@@ -706,9 +706,12 @@ __global__ __launch_bounds__(256) void k_isa_init(uint32_t *__restrict__ counter
 // FIRST: item i of the tile is (sa[base + i], base + i), its bin sa >> shift.  Otherwise the items are pairs of ONE section (a tile never
 // straddles sections: a section has a multiple of 4096 entries), the bin is the window inside the section: (suffix >> shift) & 63, and
 // the counters of that section start at counters[section * 64].
+// marked_val (FIRST only, may be null): an entry of sa with bit 31 set is the suffix sa & 0x7FFFFFFF, and its value is marked_val[position]
+// instead of its position (the suffix sort's active suffixes take the position of their group's head: no second, random pass over them)
 template <bool FIRST>
 __global__ __launch_bounds__(ISP_BLOCK) void k_isa_split(const uint32_t *__restrict__ sa, const uint64_t *__restrict__ pairs_in, size_t n, int shift,
-                                                          int section_shift, uint32_t *__restrict__ counters, uint64_t *__restrict__ pairs_out) {
+                                                          int section_shift, uint32_t *__restrict__ counters, uint64_t *__restrict__ pairs_out,
+                                                          const uint32_t *__restrict__ marked_val) {
     __shared__ uint64_t s_item[ISP_TILE];
     __shared__ uint32_t s_cnt[64], s_start[64], s_gbase[64];
     const int tid = threadIdx.x;
@@ -724,8 +727,12 @@ __global__ __launch_bounds__(ISP_BLOCK) void k_isa_split(const uint32_t *__restr
         const uint32_t i = k * ISP_BLOCK + tid;
         if (i < valid) {
             if (FIRST) {
-                const uint32_t v = sa[base + i];
-                item[k] = (static_cast<uint64_t>(v) << 32) | static_cast<uint32_t>(base + i);
+                uint32_t v = sa[base + i], value = static_cast<uint32_t>(base + i);
+                if (marked_val && (v & 0x80000000u)) {
+                    v &= 0x7FFFFFFFu;
+                    value = marked_val[base + i];
+                }
+                item[k] = (static_cast<uint64_t>(v) << 32) | value;
                 bin[k] = v >> shift;
             } else {
                 item[k] = pairs_in[base + i];
@@ -785,7 +792,8 @@ __global__ __launch_bounds__(ISA_BLOCK) void k_isa_assemble(const uint64_t *__re
 }
 
 // rank[sa[p]] = p; sa must be a permutation of 0..n-1, n <= ISA_MAX_N; scratch_a / scratch_b hold n u64 each
-static int inverse_permutation_windows(dk_ctx *ctx, const uint32_t *sa, size_t n, uint64_t *scratch_a, uint64_t *scratch_b, uint32_t *rank) {
+static int inverse_permutation_windows(dk_ctx *ctx, const uint32_t *sa, size_t n, uint64_t *scratch_a, uint64_t *scratch_b, uint32_t *rank,
+                                       const uint32_t *marked_val) {
     const int wbits = n > (size_t(1) << (10 + 12)) ? static_cast<int>(ceil_log2_u64(n)) - 12 : 10;  // at most 4096 windows of at least 1024 words
     const uint32_t nwin = static_cast<uint32_t>(div_up(n, size_t(1) << wbits));
     const bool two_levels = nwin > 64;
@@ -802,12 +810,12 @@ static int inverse_permutation_windows(dk_ctx *ctx, const uint32_t *sa, size_t n
         if (two_levels) {
             k_isa_init<<<dim3(1), dim3(256), 0, st>>>(sec_counters, nsec, wbits + 6);
             k_isa_init<<<dim3(div_up(nsec * 64, 256)), dim3(256), 0, st>>>(win_counters, nsec * 64, wbits);
-            k_isa_split<true><<<dim3(ntiles), dim3(ISP_BLOCK), 0, st>>>(sa, nullptr, n, wbits + 6, 0, sec_counters, scratch_a);
-            k_isa_split<false><<<dim3(ntiles), dim3(ISP_BLOCK), 0, st>>>(nullptr, scratch_a, n, wbits, wbits + 6, win_counters, scratch_b);
+            k_isa_split<true><<<dim3(ntiles), dim3(ISP_BLOCK), 0, st>>>(sa, nullptr, n, wbits + 6, 0, sec_counters, scratch_a, marked_val);
+            k_isa_split<false><<<dim3(ntiles), dim3(ISP_BLOCK), 0, st>>>(nullptr, scratch_a, n, wbits, wbits + 6, win_counters, scratch_b, nullptr);
             by_window = scratch_b;
         } else {
             k_isa_init<<<dim3(1), dim3(256), 0, st>>>(sec_counters, nwin, wbits);
-            k_isa_split<true><<<dim3(ntiles), dim3(ISP_BLOCK), 0, st>>>(sa, nullptr, n, wbits, 0, sec_counters, scratch_a);
+            k_isa_split<true><<<dim3(ntiles), dim3(ISP_BLOCK), 0, st>>>(sa, nullptr, n, wbits, 0, sec_counters, scratch_a, marked_val);
         }
     }
     {
@@ -825,10 +833,14 @@ static int inverse_permutation_windows(dk_ctx *ctx, const uint32_t *sa, size_t n
 
 // dst[idx[i]] = val[i] (val == nullptr: = i), i < count; idx values are distinct and < limit.  `scratch` holds count u64.
 // val == nullptr with count == limit is the inverse of a permutation: up to 2^27 entries it goes through LDS windows.
+bool inverse_through_windows(size_t n) { return n <= ISA_MAX_N; }
+
 int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, size_t count, size_t limit, uint64_t *scratch,
-                         uint64_t *scratch_b, uint32_t *dst) {
+                         uint64_t *scratch_b, uint32_t *dst, const uint32_t *marked_val) {
     if (count == 0) return DK_OK;
-    if (!val && count == limit && count <= ISA_MAX_N && scratch_b) return inverse_permutation_windows(ctx, idx, count, scratch, scratch_b, dst);
+    if (!val && count == limit && inverse_through_windows(count) && scratch_b)
+        return inverse_permutation_windows(ctx, idx, count, scratch, scratch_b, dst, marked_val);
+    if (marked_val) return ctx->fail(DK_E_INTERNAL, "scatter_u32_bucketed: marked values only in the LDS-window form");
     const ChunkPlan cp = plan_chunks(count);
     const size_t ntiles = cp.ntiles;
     const size_t mark = ctx->ws_mark();

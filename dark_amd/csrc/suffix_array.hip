@@ -119,10 +119,20 @@ __global__ __launch_bounds__(256) void k_prefix_probe(const uint8_t *__restrict_
 // ---- rank array for the doubling rounds, built once for whatever the text rounds leave -------------------------------------------
 // Every suffix that is final sits in SA; put the active ones at their (provisional) places too, store rank[SA[p]] = p for all p
 // (inverse permutation: radix_sort.hip), then give the active ones the position of their group's head.
-__global__ __launch_bounds__(256) void k_place_active(const uint32_t *__restrict__ act_idx, const uint32_t *__restrict__ act_pos, size_t count,
-                                                      uint32_t *__restrict__ sa) {
+// head_pos != nullptr: the suffix is stored with bit 31 set and head_pos[its SA position] = the position of its group's head -- the
+// inverse permutation then gives an active suffix its head's position straight away (k_isa_split), and k_rank_active is not needed
+__global__ __launch_bounds__(256) void k_place_active(const uint32_t *__restrict__ act_idx, const uint32_t *__restrict__ act_pos,
+                                                      const uint32_t *__restrict__ act_gid, const uint32_t *__restrict__ gstart, size_t count,
+                                                      uint32_t *__restrict__ sa, uint32_t *__restrict__ head_pos) {
     const size_t a = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (a < count) sa[act_pos[a]] = act_idx[a];
+    if (a >= count) return;
+    const uint32_t p = act_pos[a];
+    if (head_pos) {
+        sa[p] = act_idx[a] | 0x80000000u;
+        head_pos[p] = act_pos[gstart[act_gid[a]]];
+    } else {
+        sa[p] = act_idx[a];
+    }
 }
 __global__ __launch_bounds__(256) void k_rank_active(const uint32_t *__restrict__ act_idx, const uint32_t *__restrict__ act_pos,
                                                      const uint32_t *__restrict__ act_gid, const uint32_t *__restrict__ gstart, size_t count,
@@ -1366,12 +1376,16 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     }
     // 5b. survivors beyond that (long repeats): build the rank array the doubling rounds need
     if (active > 0 && !have_ranks) {
+        // up to 2^27 suffixes the inverse permutation goes through LDS windows and can hand every active suffix the position of its
+        // group's head by itself (marked entries of SA; pos_alt is free between rounds); above, a second pass over the active list does
+        const bool marked = inverse_through_windows(n);
+        uint32_t *head_pos = marked ? pos_alt : nullptr;
         {
-            LaunchScope ls(ctx, K_PLACE_ACTIVE, 12.0 * active);
-            k_place_active<<<dim3(div_up(active, 256)), dim3(256), 0, st>>>(vals, pos, active, d_sa);
+            LaunchScope ls(ctx, K_PLACE_ACTIVE, (marked ? 28.0 : 12.0) * active);
+            k_place_active<<<dim3(div_up(active, 256)), dim3(256), 0, st>>>(vals, pos, gid, gstart, active, d_sa, head_pos);
         }
-        DK_TRY(scatter_u32_bucketed(ctx, d_sa, nullptr, n, n, keys_alt, keys_3, rank));  // rank[SA[p]] = p (keys_alt / keys_3: free between rounds)
-        {
+        DK_TRY(scatter_u32_bucketed(ctx, d_sa, nullptr, n, n, keys_alt, keys_3, rank, head_pos));  // rank[SA[p]] = p (keys_alt / keys_3: free between rounds)
+        if (!marked) {
             LaunchScope ls(ctx, K_PLACE_ACTIVE, 16.0 * active);
             k_rank_active<<<dim3(div_up(active, 256)), dim3(256), 0, st>>>(vals, pos, gid, gstart, active, rank);
         }
