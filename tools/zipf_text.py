@@ -1,16 +1,16 @@
 """Suffix sort + BWT of a Zipf-word text: words of a 200 000-word vocabulary drawn with Zipf(1.15) frequencies, spaces, line ends, 3 % copied
 segments -- a more natural distribution of group sizes than the order-3 Markov stand-in of the bench (half of all suffixes sit in groups of
 more than 1024 members after the initial sort).  Prints per-kernel times of one profiled step and two plain timings (DK_TRACE=1 with the
-tuning build shows the rounds).  usage: python tools/zipf_text.py [N]"""
+tuning build shows the rounds).  usage: python tools/zipf_text.py [N [LETTERS]]   (LETTERS = 26, or e.g. 180 for an alphabet that needs 8-bit codes)"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
 import dark_amd
 
-def zipf_text(n, seed=5, vocab=200_000):
+def zipf_text(n, seed=5, vocab=200_000, alpha=26):
     rng = np.random.default_rng(seed)
     lens = rng.integers(2, 11, size=vocab)
-    letters = rng.integers(0, 26, size=int(lens.sum())).astype(np.uint8) + 97
+    letters = (rng.integers(0, alpha, size=int(lens.sum())) + (97 if alpha <= 26 else 48)).astype(np.uint8)  # alpha > 128: codes of 8 bits, like real enwik8
     offs = np.concatenate([[0], np.cumsum(lens)])
     # Zipf ranks
     nwords = n // 5
@@ -36,7 +36,8 @@ def zipf_text(n, seed=5, vocab=200_000):
     return out
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
-t0 = time.time(); t = zipf_text(n); print("gen %.1f s, n=%d, sigma=%d" % (time.time() - t0, len(t), len(np.unique(t))), flush=True)
+alpha = int(sys.argv[2]) if len(sys.argv) > 2 else 26
+t0 = time.time(); t = zipf_text(n, alpha=alpha); print("gen %.1f s, n=%d, sigma=%d" % (time.time() - t0, len(t), len(np.unique(t))), flush=True)
 n = len(t)
 d = torch.from_numpy(t).cuda(); out = torch.empty(n, dtype=torch.uint8, device="cuda")
 with dark_amd.Context(n) as ctx:
