@@ -97,6 +97,24 @@ def test_pathological_inputs(orc):
             assert first_diff(c.bwt_inverse(bwt, origin), t) is None, name
 
 
+def test_word_like_text(orc):
+    """Text of a few frequent words: most suffixes sit in big groups after the initial sort, the text rounds are skipped, and the general
+    rounds on ranks do the work -- the active suffixes get their head's position from the inverse permutation itself (marked SA entries),
+    and members of big groups carry the symbol in front of their suffix through the global sort (tools/zipf_text.py is this at 1e8 bytes)."""
+    rng = np.random.default_rng(21)
+    words = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 9)), dtype=np.uint8)) + b" " for _ in range(60)]
+    picks = np.minimum(rng.zipf(1.3, size=1_400_000) - 1, len(words) - 1)
+    t = np.frombuffer(b"".join(words[i] for i in picks)[:6_000_000], np.uint8).copy()
+    t[rng.integers(0, len(t), size=len(t) // 90)] = 10
+    with dark_amd.Context(len(t)) as c:
+        want = orc.sa_sais(t)
+        assert first_diff(c.suffix_array(t), want) is None
+        bwt, origin = c.bwt_forward(t)
+        wb, wo = orc.bwt_forward(t, want)
+        assert origin == wo and first_diff(bwt, wb) is None
+        assert first_diff(c.bwt_inverse(bwt, origin), t) is None
+
+
 def test_known_answers_saca_rs_411(ctx, vectors):
     # /root/reference/src/saca.rs:409-413 `detailed`, through the GPU path
     for v in vectors["reference"]["saca_rs_411_412"]:
