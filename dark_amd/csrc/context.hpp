@@ -47,6 +47,7 @@ enum KernelSlot : int {
     K_RADIX_SCATTER_TEXT,  // k_radix_scatter<false, true>: first pass, keys built from the text (13 B per pair)
     K_ISA_PARTITION,       // k_isa_init + k_isa_split<true> + k_isa_split<false> (inverse permutation through LDS windows)
     K_ISA_ASSEMBLE,        // k_isa_assemble
+    K_CHAIN,               // k_chain_extract + _ends + _tiles + _spine + _verdicts + _apply (pair chains; their sort is in the radix slots)
     K_SLOT_COUNT
 };
 static_assert(K_SLOT_COUNT <= DK_NUM_KERNEL_SLOTS, "grow DK_NUM_KERNEL_SLOTS");

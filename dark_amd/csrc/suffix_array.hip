@@ -665,6 +665,8 @@ constexpr int PL_MAX = 1 << PL_BITS;  // in-place (plateau) rounds need every gr
                                       // sizes in the slot's meta word).  2048 was measured in round 3: the 1e8 text block then skips its one
                                       // general round (a group of 1336 and 23 076 slots in groups above 256 are all that keeps it), but the
                                       // in-place rounds start one round earlier on 9.9 instead of 9.2 M slots: 11.63 against 11.55-11.66 ms
+                                      // (and again with the pair chains in front of them: 11.8 against 10.7 ms -- the chains settle fewer
+                                      // pairs at the shallower depth and the 2048-slot halos cost the sort kernel its occupancy)
 constexpr int BG_IPT = 16;
 constexpr int BG_TILE = 256 * BG_IPT;
 
@@ -1072,6 +1074,146 @@ __global__ __launch_bounds__(256) void k_plateau_ranks(const uint32_t *__restric
     if (m & PL_MOVED) rank[v & ~PL_DEAD_BIT] = pos[a - (m & PL_OFF_MASK)];
 }
 
+// ---- pair chains: what induced sorting knows and prefix doubling does not ---------------------------------------------------------------
+// A long repeat (two copies of a passage) leaves thousands of groups of TWO suffixes (a + k, a + delta + k), k = 0, 1, 2 ...: doubling
+// resolves the pair with the shortest common prefix first and needs log2(length) rounds of rank gathers for the rest.  But two suffixes
+// that start with the same symbol are ordered like the suffixes one position further on: every pair of the chain is ordered like the pair
+// behind the chain's END -- (a + K + 1, a + delta + K + 1), which is no pair any more, so its two ranks differ and decide.  One
+// comparison per chain instead of log2(length) gathers per pair:
+//   k_chain_extract  every live group of two -> a record (lower position << 32 | delta, slot of the group's head), appended in any order
+//   sort_pairs       records by lower position: the pairs of a chain become neighbours
+//   k_chain_ends     record r continues into r + 1 when that is the pair one position further on with the same delta; a record that
+//                    does not is a chain end and gets its verdict from the two ranks behind it (equal ranks = undecided: the suffixes
+//                    there sit in a bigger group; such a chain stays with the doubling rounds)
+//   k_chain_tiles / k_chain_spine / k_chain_verdicts   nearest chain end at or after every record (three-phase scan from the right)
+//                    -> the verdict goes to the head slot's byte
+//   k_chain_apply    slots in order: a decided pair writes both suffixes to SA (and L), gives the larger one its own rank and dies
+// Only groups of two are handled; everything else, and chains that end undecided, go on into the in-place rounds.
+constexpr uint8_t CH_END = 1, CH_LT = 2, CH_GT = 4;  // verdict byte: chain end | lower position is the smaller suffix | ... the larger
+constexpr int CH_TILE = 2048;
+
+__global__ __launch_bounds__(256) void k_chain_extract(const uint32_t *__restrict__ idx, const uint32_t *__restrict__ meta, size_t slots,
+                                                        uint64_t *__restrict__ rec_key, uint32_t *__restrict__ rec_slot, uint32_t *__restrict__ count) {
+    __shared__ uint32_t s_n, s_base;
+    const size_t a = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    bool take = false;
+    uint64_t key = 0;
+    if (a + 1 < slots) {
+        const uint32_t v = idx[a], m = meta[a];
+        if (!(v & PL_DEAD_BIT) && (m & PL_OFF_MASK) == 0 && ((m >> PL_BITS) & PL_OFF_MASK) == 1u) {  // head of a live group of two
+            const uint32_t w = idx[a + 1] & ~PL_DEAD_BIT;
+            const uint32_t lo = v < w ? v : w, hi = v < w ? w : v;
+            key = (static_cast<uint64_t>(lo) << 32) | (hi - lo);
+            take = true;
+        }
+    }
+    const uint32_t off = take ? atomicAdd(&s_n, 1u) : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_n ? atomicAdd(count, s_n) : 0u;
+    __syncthreads();
+    if (take) {
+        rec_key[s_base + off] = key;
+        rec_slot[s_base + off] = static_cast<uint32_t>(a);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_chain_ends(const uint64_t *__restrict__ rec_key, uint32_t m, const uint32_t *__restrict__ rank, uint32_t n,
+                                                     uint8_t *__restrict__ rec_verdict) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    const uint64_t k = rec_key[r];
+    const uint32_t lo = static_cast<uint32_t>(k >> 32), delta = static_cast<uint32_t>(k);
+    bool cont = false;
+    if (r + 1 < m) {
+        const uint64_t k1 = rec_key[r + 1];
+        cont = static_cast<uint32_t>(k1 >> 32) == lo + 1u && static_cast<uint32_t>(k1) == delta;
+    }
+    uint8_t v = 0;
+    if (!cont) {  // the pair one position further on is no group of two with this delta: its ranks decide, unless they are equal
+        const uint32_t r_lo = rank2_of(rank, lo, n, 1u), r_hi = rank2_of(rank, lo + delta, n, 1u);
+        v = CH_END | (r_lo < r_hi ? CH_LT : r_lo > r_hi ? CH_GT : 0);
+    }
+    rec_verdict[r] = v;
+}
+
+// nearest chain end at or after a record = running maximum, from the right, of (index from the right + 1) over the end records
+__global__ __launch_bounds__(256) void k_chain_tiles(const uint8_t *__restrict__ rec_verdict, uint32_t m, uint32_t *__restrict__ tile_max) {
+    __shared__ uint32_t s_red[4];
+    const uint32_t q0 = blockIdx.x * CH_TILE + threadIdx.x * 8;  // index from the right
+    uint32_t best = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t q = q0 + j;
+        if (q < m && (rec_verdict[m - 1 - q] & CH_END)) best = q + 1;
+    }
+    best = wave_max(best);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_max[blockIdx.x] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+}
+__global__ __launch_bounds__(1024) void k_chain_spine(uint32_t *__restrict__ tile_max, uint32_t ntiles) {  // exclusive running maximum over the tiles
+    __shared__ uint32_t s_tmp[16 + 1];
+    const uint32_t per = (ntiles + 1023u) / 1024u;
+    const uint32_t b0 = threadIdx.x * per, b1 = b0 + per < ntiles ? b0 + per : ntiles;
+    uint32_t mx = 0;
+    for (uint32_t b = b0; b < b1; ++b) mx = max(mx, tile_max[b]);
+    uint32_t run = block_excl_max<16>(mx, s_tmp, nullptr);
+    for (uint32_t b = b0; b < b1; ++b) {
+        const uint32_t v = tile_max[b];
+        tile_max[b] = run;
+        run = max(run, v);
+    }
+}
+__global__ __launch_bounds__(256) void k_chain_verdicts(const uint8_t *__restrict__ rec_verdict, const uint32_t *__restrict__ rec_slot, uint32_t m,
+                                                         const uint32_t *__restrict__ tile_max, uint8_t *__restrict__ slot_verdict) {
+    __shared__ uint32_t s_tmp[4 + 1];
+    const uint32_t q0 = blockIdx.x * CH_TILE + threadIdx.x * 8;
+    uint32_t e[8], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t q = q0 + j;
+        e[j] = (q < m && (rec_verdict[m - 1 - q] & CH_END)) ? q + 1 : 0u;
+        mine = max(mine, e[j]);
+    }
+    uint32_t run = max(block_excl_max<4>(mine, s_tmp, nullptr), tile_max[blockIdx.x]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t q = q0 + j;
+        if (q >= m) break;
+        run = max(run, e[j]);  // (the record at the right end of the list is always a chain end: run > 0)
+        const uint8_t v = rec_verdict[m - run] & (CH_LT | CH_GT);
+        if (v) slot_verdict[rec_slot[m - 1 - q]] = v;
+    }
+}
+
+// slots in order: the head of a decided pair settles both suffixes
+__global__ __launch_bounds__(256) void k_chain_apply(uint32_t *__restrict__ idx, const uint8_t *__restrict__ sym, const uint32_t *__restrict__ pos,
+                                                      const uint8_t *__restrict__ slot_verdict, size_t slots, uint32_t *__restrict__ sa,
+                                                      uint8_t *__restrict__ bwt, uint32_t *__restrict__ origin, uint32_t *__restrict__ rank) {
+    const size_t a = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (a + 1 >= slots) return;
+    const uint8_t v = slot_verdict[a];
+    if (!v) return;
+    const uint32_t x = idx[a], y = idx[a + 1];
+    const bool x_first = (x < y) == (v == CH_LT);  // x is the smaller SUFFIX
+    const uint32_t p0 = pos[a], p1 = pos[a + 1];
+    const uint32_t first = x_first ? x : y, second = x_first ? y : x;
+    sa[p0] = first;
+    sa[p1] = second;
+    if (bwt) {
+        const uint8_t sx = sym[a], sy = sym[a + 1];
+        bwt[p0] = x_first ? sx : sy;
+        bwt[p1] = x_first ? sy : sx;
+        if (first == 0) *origin = p0;
+        if (second == 0) *origin = p1;
+    }
+    rank[second] = p1;  // (the first keeps the pair's rank: the position of its head slot)
+    idx[a] = PL_DEAD;
+    idx[a + 1] = PL_DEAD;
+}
+
 // compaction of the in-place list (when most of its slots are dead): live slots keep their order, so groups stay contiguous
 __global__ __launch_bounds__(RR_BLOCK) void k_plateau_count(const uint32_t *__restrict__ idx, size_t slots, uint32_t *__restrict__ tile_live) {
     __shared__ uint32_t s_cnt[RR_WAVES];
@@ -1412,6 +1554,42 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
             k_to_inplace<<<dim3(div_up(slots, 256)), dim3(256), 0, st>>>(gid, gstart, slots, meta_b);
         }
         std::swap(meta_a, meta_b);  // gid was read, gid_alt written
+        // pair chains first: the groups of two that long repeats leave behind are settled by one comparison per chain
+        if (DK_KNOB("DK_PAIR_CHAINS", 1) != 0 && slots >= 2) {
+            uint64_t *rec_key = keys, *rec_key_alt = keys_alt;  // (all free at this point: nothing is sorted globally any more)
+            uint32_t *rec_slot = vals_3, *rec_slot_alt = pos_alt;
+            uint8_t *slot_verdict = reinterpret_cast<uint8_t *>(keys_3);
+            uint32_t *d_cnt = ctx->d_mail + 6;
+            DK_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), st));
+            DK_HIP(ctx, hipMemsetAsync(slot_verdict, 0, slots, st));
+            {
+                LaunchScope ls(ctx, K_CHAIN, 8.0 * slots);
+                k_chain_extract<<<dim3(div_up(slots, 256)), dim3(256), 0, st>>>(idx_a, meta_a, slots, rec_key, rec_slot, d_cnt);
+            }
+            DK_HIP(ctx, hipGetLastError());
+            DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 6, d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            DK_HIP(ctx, hipStreamSynchronize(st));
+            const uint32_t m = ctx->h_mail[6];
+            if (trace) fprintf(stderr, "[dk] pair chains: %u groups of two among %zu slots\n", m, slots);
+            if (m > 0) {
+                DK_TRY(sort_pairs(ctx, rec_key, rec_key_alt, rec_slot, rec_slot_alt, m, 32, 32 + static_cast<int>(ceil_log2_u64(n))));
+                const size_t mark2 = ctx->ws_mark();
+                const uint32_t ntiles = static_cast<uint32_t>(div_up(m, CH_TILE));
+                uint8_t *rec_verdict = ctx->ws_alloc<uint8_t>(m);
+                uint32_t *tile_max = ctx->ws_alloc<uint32_t>(ntiles);
+                if (!rec_verdict || !tile_max) return DK_E_NOMEM;
+                {
+                    LaunchScope ls(ctx, K_CHAIN, 14.0 * m + 14.0 * slots);
+                    k_chain_ends<<<dim3(div_up(m, 256)), dim3(256), 0, st>>>(rec_key, m, rank, static_cast<uint32_t>(n), rec_verdict);
+                    k_chain_tiles<<<dim3(ntiles), dim3(256), 0, st>>>(rec_verdict, m, tile_max);
+                    k_chain_spine<<<dim3(1), dim3(1024), 0, st>>>(tile_max, ntiles);
+                    k_chain_verdicts<<<dim3(ntiles), dim3(256), 0, st>>>(rec_verdict, rec_slot, m, tile_max, slot_verdict);
+                    k_chain_apply<<<dim3(div_up(slots, 256)), dim3(256), 0, st>>>(idx_a, sym_a, pos, slot_verdict, slots, d_sa, carry_bwt ? d_bwt : nullptr, d_origin, rank);
+                }
+                DK_HIP(ctx, hipGetLastError());
+                ctx->ws_release(mark2);
+            }
+        }
         unsigned launched = 0, read = 0;
         size_t live = active;
         auto launch_round = [&]() -> int {

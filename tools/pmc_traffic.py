@@ -24,11 +24,12 @@ import sys
 GATHER_KERNELS = {"k_round_local", "k_plateau_sort", "k_plateau_ranks", "k_bwt_gather", "k_radix_scan",
                   "k_big_reduce", "k_big_spine", "k_big_apply", "k_big_back", "k_rerank_scan", "k_dc_carry_a", "k_dc_carry_b", "k_dc_carry_c",
                   "k_dc_runscan", "k_dc_sweep", "k_fill_u32", "k_place_active", "k_rank_active", "k_prefix_probe", "k_to_inplace",
-                  "k_plateau_scan", "k_ibwt_walk", "k_ibwt_emit", "k_ibwt_jump", "k_isa_init"}
+                  "k_plateau_scan", "k_chain_ends", "k_chain_verdicts", "k_chain_apply", "k_ibwt_walk", "k_ibwt_emit", "k_ibwt_jump", "k_isa_init"}
 
 # dk_stats slot (dark_amd/csrc/context.hpp) of every kernel: a slot is named after its kernel, or after the common prefix of the kernels
 # one LaunchScope brackets; bench.py reports HIP-event times per slot, the rocprofv3 CSVs are per kernel
-SLOT_OF = {"k_rerank_apply_first": "k_rerank_apply", "k_rerank_scan_a": "k_rerank_scan", "k_rerank_scan_c": "k_rerank_scan",
+SLOT_OF = {"k_chain_extract": "k_chain", "k_chain_ends": "k_chain", "k_chain_tiles": "k_chain", "k_chain_spine": "k_chain", "k_chain_verdicts": "k_chain",
+           "k_chain_apply": "k_chain", "k_rerank_apply_first": "k_rerank_apply", "k_rerank_scan_a": "k_rerank_scan", "k_rerank_scan_c": "k_rerank_scan",
            "k_dc_runscan": "k_dc_carry", "k_dc_carry_a": "k_dc_carry", "k_dc_carry_b": "k_dc_carry", "k_dc_carry_c": "k_dc_carry",
            "k_fill_u32": "k_dc_carry", "k_ibwt_scan_a": "k_ibwt_hist", "k_ibwt_scan_b": "k_ibwt_hist", "k_ibwt_scan_c": "k_ibwt_hist",
            "k_big_reduce": "k_big_classify", "k_big_spine": "k_big_classify", "k_big_apply": "k_big_classify",
