@@ -695,7 +695,7 @@ __global__ __launch_bounds__(RS_BLOCK) void k_bucket_store(const uint64_t *__res
 constexpr int ISA_BLOCK = 1024;
 constexpr int ISA_WBITS = 15;                 // largest window = 32768 words = 128 KiB of LDS
 constexpr size_t ISA_MAX_N = size_t(1) << (ISA_WBITS + 12);  // at most 64 sections x 64 windows
-constexpr int ISP_BLOCK = 256, ISP_IPT = 16, ISP_TILE = ISP_BLOCK * ISP_IPT;  // 4096 pairs per workgroup
+constexpr int ISP_BLOCK = 256, ISP_IPT = 16, ISP_TILE = ISP_BLOCK * ISP_IPT;  // 4096 pairs per workgroup (8192 with 512 threads: the same 0.95 ms)
 
 // counters[d] = first index of bin d (bins of 2^shift entries)
 __global__ __launch_bounds__(256) void k_isa_init(uint32_t *__restrict__ counters, uint32_t bins, int shift) {

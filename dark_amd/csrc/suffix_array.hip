@@ -1092,30 +1092,40 @@ __global__ __launch_bounds__(256) void k_plateau_ranks(const uint32_t *__restric
 constexpr uint8_t CH_END = 1, CH_LT = 2, CH_GT = 4;  // verdict byte: chain end | lower position is the smaller suffix | ... the larger
 constexpr int CH_TILE = 2048;
 
+// (a workgroup takes CH_EXTRACT x 256 slots and reserves its place in the record list with ONE global atomic: one per 256 slots --
+// 36 000 atomics on one address for the 9.2 M slots of the 1e8 text block -- was 0.41 ms of a kernel that reads 73 MB)
+constexpr int CH_EXTRACT = 16;
 __global__ __launch_bounds__(256) void k_chain_extract(const uint32_t *__restrict__ idx, const uint32_t *__restrict__ meta, size_t slots,
                                                         uint64_t *__restrict__ rec_key, uint32_t *__restrict__ rec_slot, uint32_t *__restrict__ count) {
     __shared__ uint32_t s_n, s_base;
-    const size_t a = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    bool take = false;
-    uint64_t key = 0;
-    if (a + 1 < slots) {
-        const uint32_t v = idx[a], m = meta[a];
-        if (!(v & PL_DEAD_BIT) && (m & PL_OFF_MASK) == 0 && ((m >> PL_BITS) & PL_OFF_MASK) == 1u) {  // head of a live group of two
-            const uint32_t w = idx[a + 1] & ~PL_DEAD_BIT;
-            const uint32_t lo = v < w ? v : w, hi = v < w ? w : v;
-            key = (static_cast<uint64_t>(lo) << 32) | (hi - lo);
-            take = true;
+    uint64_t key[CH_EXTRACT];
+    uint32_t off[CH_EXTRACT];
+    uint32_t took = 0;  // bit c: chunk c gave this thread a record
+#pragma unroll
+    for (int c = 0; c < CH_EXTRACT; ++c) {
+        const size_t a = (static_cast<size_t>(blockIdx.x) * CH_EXTRACT + c) * 256 + threadIdx.x;
+        if (a + 1 < slots) {
+            const uint32_t v = idx[a], m = meta[a];
+            if (!(v & PL_DEAD_BIT) && (m & PL_OFF_MASK) == 0 && ((m >> PL_BITS) & PL_OFF_MASK) == 1u) {  // head of a live group of two
+                const uint32_t w = idx[a + 1] & ~PL_DEAD_BIT;
+                const uint32_t lo = v < w ? v : w, hi = v < w ? w : v;
+                key[c] = (static_cast<uint64_t>(lo) << 32) | (hi - lo);
+                off[c] = atomicAdd(&s_n, 1u);
+                took |= 1u << c;
+            }
         }
     }
-    const uint32_t off = take ? atomicAdd(&s_n, 1u) : 0u;
     __syncthreads();
     if (threadIdx.x == 0) s_base = s_n ? atomicAdd(count, s_n) : 0u;
     __syncthreads();
-    if (take) {
-        rec_key[s_base + off] = key;
-        rec_slot[s_base + off] = static_cast<uint32_t>(a);
+#pragma unroll
+    for (int c = 0; c < CH_EXTRACT; ++c) {
+        if (took & (1u << c)) {
+            rec_key[s_base + off[c]] = key[c];
+            rec_slot[s_base + off[c]] = static_cast<uint32_t>((static_cast<size_t>(blockIdx.x) * CH_EXTRACT + c) * 256 + threadIdx.x);
+        }
     }
 }
 
@@ -1520,7 +1530,9 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     if (active > 0 && !have_ranks) {
         // up to 2^27 suffixes the inverse permutation goes through LDS windows and can hand every active suffix the position of its
         // group's head by itself (marked entries of SA; pos_alt is free between rounds); above, a second pass over the active list does
-        const bool marked = inverse_through_windows(n);
+        // (worth it from a quarter of all suffixes active: the marked form costs the first split 0.17 ms per 1e8 suffixes, the second pass
+        // it replaces 0.14 ms per 1e7 active ones)
+        const bool marked = inverse_through_windows(n) && active * 4 > n;
         uint32_t *head_pos = marked ? pos_alt : nullptr;
         {
             LaunchScope ls(ctx, K_PLACE_ACTIVE, (marked ? 28.0 : 12.0) * active);
@@ -1564,7 +1576,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
             DK_HIP(ctx, hipMemsetAsync(slot_verdict, 0, slots, st));
             {
                 LaunchScope ls(ctx, K_CHAIN, 8.0 * slots);
-                k_chain_extract<<<dim3(div_up(slots, 256)), dim3(256), 0, st>>>(idx_a, meta_a, slots, rec_key, rec_slot, d_cnt);
+                k_chain_extract<<<dim3(div_up(slots, 256 * CH_EXTRACT)), dim3(256), 0, st>>>(idx_a, meta_a, slots, rec_key, rec_slot, d_cnt);
             }
             DK_HIP(ctx, hipGetLastError());
             DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 6, d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
