@@ -3,7 +3,7 @@ the same bytes.
   DK_ENTROPY_THREADS=1|2|4  host coder: one thread, models | coder on two, the four-stage pipeline of the dark model (product library)
 The device-side switches exist in the TUNING build only (dark_amd/libdark_amd_tuning.so, -DDK_TUNING: csrc/context.hpp DK_KNOB); the
 product library has them compiled in as constants:
-  DK_XCD=0 plain tile order | DK_DIGIT_PLANE=1 histograms from the digit plane at every size | DK_PLATEAU=0 general doubling rounds only
+  DK_XCD=0 plain tile order | DK_DIGIT_PLANE=1 histograms from the digit plane at every size | DK_PLATEAU=0 general doubling rounds only | DK_PAIR_CHAINS=0 no pair chains in front of the in-place rounds
   DK_BWT_CARRY=0 L gathered from the suffix array instead of riding with the suffixes | DK_PREFIX=0|1|2|3 prefix length of the initial sort"""
 import os
 import subprocess
@@ -147,7 +147,7 @@ def test_entropy_error_paths_return_codes(threads):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"DK_XCD": "0"}, {"DK_DIGIT_PLANE": "1"}, {"DK_PLATEAU": "0"}, {"DK_BWT_CARRY": "0"},
-                                 {"DK_PLATEAU": "0", "DK_BWT_CARRY": "0"}])
+                                 {"DK_PLATEAU": "0", "DK_BWT_CARRY": "0"}, {"DK_PAIR_CHAINS": "0"}, {"DK_PAIR_CHAINS": "1", "DK_BWT_CARRY": "0"}])
 def test_gpu_variants_match_oracle(env):
     _run(GPU_SNIPPET, env, tuning=True)
 
