@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "context.hpp"
+#include <atomic>
 #include "entropy.hpp"
 
 using namespace dk;
@@ -65,10 +66,12 @@ struct ForwardResult {
     const uint8_t *sym = nullptr;
     const uint8_t *rank = nullptr;
     const uint32_t *run_end = nullptr;
+    const std::atomic<size_t> *ready = nullptr;  // set: dist / sym are still arriving (forward_to_stream with overlap)
 };
 
 // slot < 0: the context's single staging buffer; otherwise the batch staging slot of that index
-int forward_to_stream(dk_ctx *ctx, const uint8_t *d_text, size_t n, bool want_ctx_fields, ForwardResult *fr, int slot = -1) {
+// overlap: the caller can work with a stream that is still arriving (ForwardResult::ready) and synchronises the stream afterwards
+int forward_to_stream(dk_ctx *ctx, const uint8_t *d_text, size_t n, bool want_ctx_fields, ForwardResult *fr, int slot = -1, bool overlap = false) {
     hipStream_t st = ctx->stream;
     uint8_t *d_bwt = ctx->ws_alloc<uint8_t>(n);
     if (!d_bwt) return DK_E_NOMEM;
@@ -99,6 +102,29 @@ int forward_to_stream(dk_ctx *ctx, const uint8_t *d_text, size_t n, bool want_ct
         DK_TRY(ctx->ensure_slot(static_cast<size_t>(slot), off_end + 4 * m + 64));
         stage = ctx->slots[static_cast<size_t>(slot)].h;
     }
+    fr->ready = nullptr;
+    if (overlap && !want_ctx_fields && m >= (size_t(1) << 21)) {
+        // A large single block: the entropy stage starts on the first piece while the rest is on its way.  Every piece's two copies are
+        // followed by a host function that moves the frontier (DcStream::ready); the stream is synchronised by the caller after coding.
+        constexpr size_t PIECES = 16;
+        ctx->d2h_ready.store(0, std::memory_order_relaxed);
+        ctx->d2h_marks.resize(PIECES);
+        for (size_t c = 0; c < PIECES; ++c) {
+            const size_t k0 = m * c / PIECES, k1 = m * (c + 1) / PIECES;
+            DK_HIP(ctx, hipMemcpyAsync(stage + 4 * k0, d_dist + k0, 4 * (k1 - k0), hipMemcpyDeviceToHost, st));
+            DK_HIP(ctx, hipMemcpyAsync(stage + off_sym + k0, d_sym + k0, k1 - k0, hipMemcpyDeviceToHost, st));
+            ctx->d2h_marks[c] = dk_ctx::D2hMark{&ctx->d2h_ready, k1};
+            DK_HIP(ctx, hipLaunchHostFunc(st, [](void *p) {
+                auto *mk = static_cast<dk_ctx::D2hMark *>(p);
+                mk->frontier->store(mk->value, std::memory_order_release);
+            }, &ctx->d2h_marks[c]));
+        }
+        ctx->stats.ms_d2h = t4.ms();  // (time to enqueue: the transfer itself hides behind the coder)
+        fr->dist = reinterpret_cast<const uint32_t *>(stage);
+        fr->sym = reinterpret_cast<const uint8_t *>(stage + off_sym);
+        fr->ready = &ctx->d2h_ready;
+        return DK_OK;
+    }
     DK_HIP(ctx, hipMemcpyAsync(stage, d_dist, 4 * m, hipMemcpyDeviceToHost, st));
     DK_HIP(ctx, hipMemcpyAsync(stage + off_sym, d_sym, m, hipMemcpyDeviceToHost, st));
     if (want_ctx_fields) {
@@ -128,12 +154,17 @@ int block_encode_common(dk_ctx *ctx, int model_id, const uint8_t *d_text, size_t
         return ctx->fail(DK_E_MODEL, "model %d cannot code blocks of %zu bytes without losing bits (limit %llu)", model_id, n,
                          static_cast<unsigned long long>(model_max_block(model_id)));
     ForwardResult fr;
-    DK_TRY(forward_to_stream(ctx, d_text, n, model_id == DK_MODEL_RAWDC, &fr));
+    DK_TRY(forward_to_stream(ctx, d_text, n, model_id == DK_MODEL_RAWDC, &fr, -1, true));
     ctx->last_flags = block_flags(fr.init, n);
     Timer t;
     DcStream s;
     s.n = n; s.init = fr.init; s.dist = fr.dist; s.sym = fr.sym; s.rank = fr.rank; s.run_end = fr.run_end; s.m = fr.m; s.origin = fr.origin;
+    s.ready = fr.ready;
     int rc = encode_block_stream(model_id, s, out, out_cap, out_len);
+    if (fr.ready) {  // (a coder that gave up early must not leave copies and host functions of this call behind)
+        const hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess && !rc) rc = DK_E_HIP;
+    }
     ctx->stats.ms_entropy = t.ms();
     ctx->stats.entropy_threads = static_cast<uint32_t>(dk::last_entropy_threads());
     ctx->stats.entropy_l3_group = dk::last_entropy_group();

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdint>
@@ -79,6 +80,10 @@ struct dk_ctx {
     int ensure_slot(size_t index, size_t bytes);
     std::string err;
     struct dk_batch *live_batch = nullptr;  // the streaming batch open on this context (dk_batch_begin .. dk_batch_finish), if any
+    // D2H of a large block's distance stream in pieces: a host function behind every piece moves the frontier the host coder waits at
+    struct D2hMark { std::atomic<size_t> *frontier; size_t value; };
+    std::atomic<size_t> d2h_ready{0};
+    std::vector<D2hMark> d2h_marks;
     unsigned last_flags = 0;   // DK_FLAG_* of the block the last block encode coded
     size_t last_consumed = 0;  // bytes of coded stream the last block decode read (records can be concatenated)
     dk_stats stats{};

@@ -363,8 +363,19 @@ int write_stream(M &model, const DcStream &s, E &e) {
             active = true;
         }
     }
-    for (size_t k = 0; k < s.m; ++k)  // src/block/dc.rs:82-85
+    size_t have = s.ready ? s.ready->load(std::memory_order_acquire) : s.m;  // (entries that have arrived from the GPU: DcStream::ready)
+    for (size_t k = 0; k < s.m; ++k) {  // src/block/dc.rs:82-85
+        for (unsigned spins = 0; k >= have; have = s.ready->load(std::memory_order_acquire)) {
+            if (++spins < (1u << 14)) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            } else {
+                std::this_thread::yield();
+            }
+        }
         if (!code(s.dist[k], s.sym[k])) return fail();
+    }
     if (!code(s.origin, 0)) return fail();  // src/block/dc.rs:88 under CTX_0
     if (!e.finish()) return e.error();
     return DK_OK;

@@ -6,6 +6,7 @@
 // src/model/{dark,exp,ybs,simple,raw}.rs, the stream layout of src/block/dc.rs:53-90,121-151, compress::bwt::dc::decode
 // (src/block/dc.rs:146-150) and the in-repo bitwise coder src/entropy/{mod,ari}.rs.
 #pragma once
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
@@ -475,6 +476,9 @@ struct DcStream {          // what the GPU DC stage hands to the entropy stage
     const uint32_t *run_end = nullptr;  // [m] position of each entry (RAWDC only: distance_limit = n - pos)
     size_t m = 0;
     uint32_t origin = 0;
+    // may be null: dist / sym are still arriving from the GPU -- *ready = the number of entries that are there (grows to m); every
+    // thread that walks the stream waits at this frontier (write_stream)
+    const std::atomic<size_t> *ready = nullptr;
 };
 // src/block/dc.rs:53-90: init-table RLE header, distances, origin, finish
 // host_threads: 0 = automatic (two threads for large blocks when a partner core sharing the L3 can be pinned), 1 = one thread
