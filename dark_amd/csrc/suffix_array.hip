@@ -1523,7 +1523,9 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
         // symbols each, where a doubling round doubles the depth for the same sort -- go straight to the ranks
         if (nbig * 2 > active) break;
         int adv = 0;
-        DK_TRY(run_round(std::min(spk, 63 / bits), &adv));
+        // (small alphabets, coded keys: no more symbols than the depth reached so far -- the round doubles the depth like a doubling round
+        // would, and its keys cost a table lookup per symbol: 2^28 ACGT took 31 symbols per survivor where 16 separate all but the repeats)
+        DK_TRY(run_round(std::min<int>(std::min(spk, 63 / bits), static_cast<int>(std::min<uint64_t>(h, 64))), &adv));
         h += static_cast<uint64_t>(adv);
     }
     // 5b. survivors beyond that (long repeats): build the rank array the doubling rounds need
