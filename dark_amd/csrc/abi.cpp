@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "context.hpp"
+#include <cstdlib>
 #include <atomic>
 #include "entropy.hpp"
 
