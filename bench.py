@@ -33,7 +33,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="enwik8_like_1e8",
-                    help="enwik8_like_1e8 (BASELINE configs[1], default) | book1_like_768771 | acgt_2p28 | enwik9_block_125e6 | random_2p30")
+                    help="enwik8_like_1e8 (BASELINE configs[1], default) | book1_like_768771 | acgt_2p28 | enwik9_block_125e6 | random_2p30 | "
+                         "wordlike_1e8 (Zipf-word text with an 8-bit alphabet: what real text does to the suffix sort, tracked beside the headline)")
     ap.add_argument("--n", type=int, default=0, help="override the block size (debug)")
     ap.add_argument("--model", default="dark")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -127,6 +128,7 @@ def make_block(workload, seed_offset, n_override):
         "acgt_2p28": (datagen.acgt, 1 << 28, 3),
         "enwik9_block_125e6": (datagen.wiki_like, 125_000_000, 40),
         "random_2p30": (datagen.random_bytes, 1 << 30, 50),
+        "wordlike_1e8": (datagen.word_like, 100_000_000, 5),
     }
     fn, n, seed = gens[workload]
     return fn(n, seed + seed_offset)

@@ -71,6 +71,7 @@ SIGNATURES = {
     "dk_set_entropy_threads": (_i, [_i]),
     "dk_host_l3_groups": (_i, [_i]),
     "dk_last_entropy_info": (None, [C.POINTER(_i), C.POINTER(_i)]),
+    "dk_dbg_stream_encode_gated": (_i, [_i, _sz, _vp, _vp, _vp, _sz, C.c_uint32, _vp, _sz, _szp, _vp, C.c_uint, _i]),
     "dk_dbg_sort_pairs": (_i, [_vp, _vp, _vp, _sz, _i, _i]),
 }
 

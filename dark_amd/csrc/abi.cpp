@@ -37,6 +37,10 @@ int check_n(dk_ctx *ctx, size_t n) {
     if (n > ctx->max_n) return ctx->fail(DK_E_ARG, "block of %zu bytes exceeds the context capacity %zu", n, ctx->max_n);
     return DK_OK;
 }
+#ifndef DK_D2H_OVERLAP
+#define DK_D2H_OVERLAP 1  // the distance stream of a large single block leaves the GPU in pieces while the host coder already runs (0: A/B builds)
+#endif
+
 size_t workspace_bytes(size_t max_n) {
     // Peak of the bump allocator, reached inside the suffix sort of a host-pointer block call (every term is one ws_alloc of the call):
     //   text copy                                   n     (host entry points only)
@@ -104,23 +108,32 @@ int forward_to_stream(dk_ctx *ctx, const uint8_t *d_text, size_t n, bool want_ct
         stage = ctx->slots[static_cast<size_t>(slot)].h;
     }
     fr->ready = nullptr;
-    if (overlap && !want_ctx_fields && m >= (size_t(1) << 21)) {
+    if (DK_D2H_OVERLAP && overlap && !want_ctx_fields && m >= (size_t(1) << 21)) {
         // A large single block: the entropy stage starts on the first piece while the rest is on its way.  Every piece's two copies are
         // followed by a host function that moves the frontier (DcStream::ready); the stream is synchronised by the caller after coding.
+        // If anything fails to enqueue, whatever was enqueued is waited for before the error is returned: its host functions point into
+        // this context (d2h_marks, d2h_ready), which the next call reuses.
         constexpr size_t PIECES = 16;
         ctx->d2h_ready.store(0, std::memory_order_relaxed);
         ctx->d2h_marks.resize(PIECES);
-        for (size_t c = 0; c < PIECES; ++c) {
+        hipError_t e = hipSuccess;
+        for (size_t c = 0; c < PIECES && e == hipSuccess; ++c) {
             const size_t k0 = m * c / PIECES, k1 = m * (c + 1) / PIECES;
-            DK_HIP(ctx, hipMemcpyAsync(stage + 4 * k0, d_dist + k0, 4 * (k1 - k0), hipMemcpyDeviceToHost, st));
-            DK_HIP(ctx, hipMemcpyAsync(stage + off_sym + k0, d_sym + k0, k1 - k0, hipMemcpyDeviceToHost, st));
+            e = hipMemcpyAsync(stage + 4 * k0, d_dist + k0, 4 * (k1 - k0), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(stage + off_sym + k0, d_sym + k0, k1 - k0, hipMemcpyDeviceToHost, st);
             ctx->d2h_marks[c] = dk_ctx::D2hMark{&ctx->d2h_ready, k1};
-            DK_HIP(ctx, hipLaunchHostFunc(st, [](void *p) {
-                auto *mk = static_cast<dk_ctx::D2hMark *>(p);
-                mk->frontier->store(mk->value, std::memory_order_release);
-            }, &ctx->d2h_marks[c]));
+            if (e == hipSuccess)
+                e = hipLaunchHostFunc(st, [](void *p) {
+                    auto *mk = static_cast<dk_ctx::D2hMark *>(p);
+                    mk->frontier->store(mk->value, std::memory_order_release);
+                }, &ctx->d2h_marks[c]);
         }
-        ctx->stats.ms_d2h = t4.ms();  // (time to enqueue: the transfer itself hides behind the coder)
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(st);
+            ctx->d2h_ready.store(dk::DC_STREAM_POISON, std::memory_order_release);
+            return ctx->fail(DK_E_HIP, "D2H of the distance stream: %s", hipGetErrorString(e));
+        }
+        ctx->stats.ms_d2h = t4.ms();  // time to enqueue; block_encode_common adds what it waits for the stream after coding
         fr->dist = reinterpret_cast<const uint32_t *>(stage);
         fr->sym = reinterpret_cast<const uint8_t *>(stage + off_sym);
         fr->ready = &ctx->d2h_ready;
@@ -162,11 +175,15 @@ int block_encode_common(dk_ctx *ctx, int model_id, const uint8_t *d_text, size_t
     s.n = n; s.init = fr.init; s.dist = fr.dist; s.sym = fr.sym; s.rank = fr.rank; s.run_end = fr.run_end; s.m = fr.m; s.origin = fr.origin;
     s.ready = fr.ready;
     int rc = encode_block_stream(model_id, s, out, out_cap, out_len);
+    double ms_wait = 0.0;
     if (fr.ready) {  // (a coder that gave up early must not leave copies and host functions of this call behind)
+        Timer tw;
         const hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess && !rc) rc = DK_E_HIP;
+        ms_wait = tw.ms();
+        ctx->stats.ms_d2h += ms_wait;
     }
-    ctx->stats.ms_entropy = t.ms();
+    ctx->stats.ms_entropy = t.ms() - ms_wait;
     ctx->stats.entropy_threads = static_cast<uint32_t>(dk::last_entropy_threads());
     ctx->stats.entropy_l3_group = dk::last_entropy_group();
     if (rc == DK_E_CAPACITY) return ctx->fail(rc, "output buffer of %zu bytes is too small", out_cap);
@@ -906,6 +923,16 @@ void dk_last_entropy_info(int *threads, int *l3_group) {
 }
 
 // ---- debug ------------------------------------------------------------------------------------------------------------------
+int dk_dbg_stream_encode_gated(int model_id, size_t n, const uint32_t init[256], const uint32_t *dist, const uint8_t *sym, size_t m, uint32_t origin,
+                               uint8_t *out, size_t out_cap, size_t *out_len, const size_t *ready, unsigned stall_ms, int host_threads) {
+    if (!ready) return DK_E_ARG;
+    static_assert(sizeof(std::atomic<size_t>) == sizeof(size_t) && std::atomic<size_t>::is_always_lock_free, "the caller's word is read as an atomic");
+    DcStream s;
+    s.n = n; s.init = init; s.dist = dist; s.sym = sym; s.m = m; s.origin = origin;
+    s.ready = reinterpret_cast<const std::atomic<size_t> *>(ready);
+    s.stall_ms = stall_ms;
+    return encode_block_stream(model_id, s, out, out_cap, out_len, host_threads);
+}
 int dk_dbg_sort_pairs(dk_ctx *ctx, uint64_t *keys, uint32_t *vals, size_t count, int begin_bit, int end_bit) {
     DK_TRY(begin_call(ctx));
     ScopedCall sc(ctx);

@@ -338,6 +338,31 @@ uint64_t model_max_block(int model_id) {
 // ------------------------------------------------------------------------------------------------------------------
 namespace {
 
+// A stream that is still arriving from the GPU: wait until more than k entries are there (*have = the frontier).  The frontier is moved
+// by host functions on the context's HIP stream; DC_STREAM_POISON means the producer gave up (a copy failed, the stream reported an
+// error), and a frontier that stands still for stall_ms (DcStream::stall_ms, default 20 s: a D2H piece of a 2 GiB block takes 40 ms)
+// means the stream is hung or has faulted: DK_E_HIP either way -- no coder thread spins for ever.
+__attribute__((noinline)) int wait_for_entries(const DcStream &s, size_t k, size_t *have) {
+    size_t h = s.ready->load(std::memory_order_acquire);
+    std::chrono::steady_clock::time_point since;
+    bool timing = false;
+    const double limit_ms = static_cast<double>(s.stall_ms ? s.stall_ms : 20000u);
+    for (unsigned spins = 0; h <= k; h = s.ready->load(std::memory_order_acquire)) {
+        if (++spins < (1u << 14)) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+            continue;
+        }
+        std::this_thread::yield();
+        if (!timing) { since = std::chrono::steady_clock::now(); timing = true; }
+        else if ((spins & 0xFFu) == 0 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - since).count() > limit_ms) return DK_E_HIP;
+    }
+    if (h == DC_STREAM_POISON) return DK_E_HIP;
+    *have = h < s.m ? h : s.m;
+    return DK_OK;
+}
+
 // src/block/dc.rs:54-90 with any model M
 template <class M, class E>
 int write_stream(M &model, const DcStream &s, E &e) {
@@ -363,18 +388,17 @@ int write_stream(M &model, const DcStream &s, E &e) {
             active = true;
         }
     }
-    size_t have = s.ready ? s.ready->load(std::memory_order_acquire) : s.m;  // (entries that have arrived from the GPU: DcStream::ready)
-    for (size_t k = 0; k < s.m; ++k) {  // src/block/dc.rs:82-85
-        for (unsigned spins = 0; k >= have; have = s.ready->load(std::memory_order_acquire)) {
-            if (++spins < (1u << 14)) {
-#if defined(__x86_64__)
-                __builtin_ia32_pause();
-#endif
-            } else {
-                std::this_thread::yield();
-            }
+    // src/block/dc.rs:82-85.  A stream that is still arriving from the GPU (DcStream::ready) is walked stretch by stretch: the wait sits
+    // between the stretches, the loop over a stretch is the loop over a finished stream (a frontier check per distance inside it cost the
+    // four-stage pipeline 3 % on the GPU box: one more live value in loops that are short of registers).
+    for (size_t k = 0; k < s.m;) {
+        size_t have = s.m;
+        if (s.ready) {
+            const int rc = wait_for_entries(s, k, &have);
+            if (rc != DK_OK) return rc;
         }
-        if (!code(s.dist[k], s.sym[k])) return fail();
+        for (; k < have; ++k)
+            if (!code(s.dist[k], s.sym[k])) return fail();
     }
     if (!code(s.origin, 0)) return fail();  // src/block/dc.rs:88 under CTX_0
     if (!e.finish()) return e.error();

@@ -479,7 +479,9 @@ struct DcStream {          // what the GPU DC stage hands to the entropy stage
     // may be null: dist / sym are still arriving from the GPU -- *ready = the number of entries that are there (grows to m); every
     // thread that walks the stream waits at this frontier (write_stream)
     const std::atomic<size_t> *ready = nullptr;
+    unsigned stall_ms = 0;  // a frontier that does not move for this long ends the pass with DK_E_HIP (0 = 20 s)
 };
+constexpr size_t DC_STREAM_POISON = ~static_cast<size_t>(0);  // *ready: the producer gave up, nothing more will arrive
 // src/block/dc.rs:53-90: init-table RLE header, distances, origin, finish
 // host_threads: 0 = automatic (two threads for large blocks when a partner core sharing the L3 can be pinned), 1 = one thread
 int encode_block_stream(int model_id, const DcStream &s, uint8_t *out, size_t cap, size_t *out_len, int host_threads = 0);

@@ -61,10 +61,48 @@ def random_bytes(n=1 << 30, seed=50):
     return rng.integers(0, 256, size=n, dtype=np.uint8)
 
 
+def word_like(n=100_000_000, seed=5, vocab=200_000, alpha=180):
+    """word-like text (what real enwik8 does to a suffix sorter and the Markov stand-in does not): words of a `vocab`-word
+    vocabulary (2..10 letters each) drawn with Zipf(1.15) frequencies and separated by spaces, a line end every 80 bytes on average, 3 % of
+    the length overwritten by copied 64 B - 4 KiB segments.  alpha = number of distinct letters: 180 gives 182 distinct bytes, so symbol codes
+    take 8 bits like on real enwik8 (seven symbols in the initial sort key); 26 gives a 5-bit alphabet.  No byte 0xFF."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(2, 11, size=vocab)
+    letters = (rng.integers(0, alpha, size=int(lens.sum())) + (97 if alpha <= 26 else 48)).astype(np.uint8)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    nwords = max(n // 5, 16)
+    ranks = np.minimum(rng.zipf(1.15, size=nwords) - 1, vocab - 1)
+    wl = lens[ranks] + 1
+    total = int(wl.sum())
+    if total < n:
+        raise ValueError("word_like: %d words make %d bytes, fewer than n = %d" % (nwords, total, n))
+    out = np.full(total, 32, dtype=np.uint8)
+    starts = np.concatenate([[0], np.cumsum(wl)[:-1]])
+    for L in range(2, 11):  # fill the letters of all words of one length at a time
+        sel = np.nonzero(lens[ranks] == L)[0]
+        if len(sel) == 0:
+            continue
+        src = offs[ranks[sel]][:, None] + np.arange(L)[None, :]
+        dst = starts[sel][:, None] + np.arange(L)[None, :]
+        out[dst.reshape(-1)] = letters[src.reshape(-1)]
+    out = np.ascontiguousarray(out[:n])
+    if n >= 80:
+        out[rng.integers(0, n, size=n // 80)] = 10
+    budget = n // 33
+    while budget > 0 and n > 8192:
+        ln = int(rng.integers(64, 4097))
+        s = int(rng.integers(0, n - ln))
+        d = int(rng.integers(0, n - ln))
+        out[d:d + ln] = out[s:s + ln].copy()
+        budget -= ln
+    return out
+
+
 WORKLOADS = {
     "book1_like_768771": lambda seed=1: english_like(768771, seed),
     "enwik8_like_1e8": lambda seed=2: wiki_like(100_000_000, seed),
     "acgt_2p28": lambda seed=3: acgt(1 << 28, seed),
     "enwik9_block_125e6": lambda seed=40: wiki_like(125_000_000, seed),
     "random_2p30": lambda seed=50: random_bytes(1 << 30, seed),
+    "wordlike_1e8": lambda seed=5: word_like(100_000_000, seed),
 }

@@ -182,6 +182,9 @@ int dk_raw_stream_decode(int raw_model, const uint8_t *in, size_t in_len, size_t
 typedef struct dk_stats {
     /* wall-clock stage times of the last block call on this context, milliseconds */
     double ms_h2d, ms_sa, ms_bwt, ms_dc, ms_d2h, ms_entropy, ms_ibwt, ms_total;
+    /* ms_d2h of a large single block (>= 2^21 distances, dk_block_encode / dk_dev_block_encode): the distance stream leaves the GPU in pieces
+     * while the host coder already runs, so ms_d2h = the time to enqueue the copies + the time the call waits for the stream after coding
+     * (normally microseconds: the transfer hides behind the coder); the coder's own waits at the frontier are part of ms_entropy. */
     uint32_t rounds;          /* prefix-doubling rounds executed by the last suffix sort */
     uint32_t sort_passes;     /* radix passes executed by the last suffix sort */
     uint64_t sorted_elements; /* sum over passes of elements moved */
@@ -212,6 +215,13 @@ int dk_host_l3_groups(int min_cores);
 void dk_last_entropy_info(int *threads, int *l3_group);
 
 /* ---- stage-level debug entry points used by the parity tests ------------------------------------------------ */
+/* dk_stream_encode on a distance stream that is still ARRIVING, the way dk_dev_block_encode feeds its host coder while the D2H copies
+ * of a large block run: *ready (read atomically; another thread of the caller moves it) = entries of dist / sym that are there.  The
+ * coder waits at that frontier; (size_t)-1 there = "the producer gave up", and a frontier that stands still for stall_ms milliseconds
+ * (0 = 20 s) = "the stream hangs": DK_E_HIP in both cases instead of a coder that spins for ever.  host_threads: 0 automatic | 1 | 2 | 4. */
+int dk_dbg_stream_encode_gated(int model_id, size_t n, const uint32_t init[256], const uint32_t *dist, const uint8_t *sym, size_t m,
+                               uint32_t origin, uint8_t *out, size_t out_cap, size_t *out_len, const size_t *ready, unsigned stall_ms,
+                               int host_threads);
 /* stable LSD radix sort of (u64 key, u32 value) pairs on bits [begin_bit, end_bit) -- the workhorse of the suffix sort */
 int dk_dbg_sort_pairs(dk_ctx *ctx, uint64_t *keys, uint32_t *vals, size_t count, int begin_bit, int end_bit);
 

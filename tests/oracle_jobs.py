@@ -17,6 +17,7 @@ SPECS = {
     "enwik9_block_125e6": (lambda: datagen.wiki_like(125_000_000, 40), True),
     "acgt_2p28": (lambda: datagen.acgt(1 << 28, 3), True),
     "random_2p30": (lambda: datagen.random_bytes(1 << 30, 50), True),
+    "wordlike_1e8": (lambda: datagen.word_like(100_000_000, 5), True),
 }
 # small stand-ins with the same code path, for checking this module itself on the CPU (tests/test_oracle.py)
 SPECS_SMALL = {

@@ -232,3 +232,57 @@ def test_bbb_raw_stream_matches_oracle(orc, license_bytes):
     with pytest.raises(dark_amd.DarkError) as e:
         model.raw_stream_encode(b"abc", 0, raw_model=0)  # the dump model codes nothing: not a stream model
     assert e.value.code == _lib.DK_E_MODEL
+
+
+def _gated_encode(n, init, dist, sym, origin, ready, stall_ms, threads):
+    lib = _lib.load()
+    out = np.empty(8 * len(dist) + 8192, dtype=np.uint8)
+    ln = C.c_size_t(0)
+    rc = lib.dk_dbg_stream_encode_gated(0, n, init.ctypes.data, dist.ctypes.data, sym.ctypes.data, len(dist), origin, out.ctypes.data, len(out),
+                                        C.byref(ln), C.addressof(ready), stall_ms, threads)
+    return rc, out[:ln.value].tobytes()
+
+
+@pytest.mark.parametrize("threads", [1, 2, 4])
+def test_stream_that_is_still_arriving(threads):
+    """ADVICE r3 (abi.cpp:113): the host coder of a large block starts while the distance stream is still on its way from the GPU and waits
+    at a frontier the HIP stream's host functions move.  Here another thread moves the frontier: in steps (same bytes as the finished
+    stream, whatever the thread form), not at all (the coder gives up with DK_E_HIP after stall_ms), or to the poison value."""
+    import threading
+    import time
+    rng = np.random.default_rng(12)
+    m = 300_000
+    n = 1 << 22
+    dist = (rng.integers(0, 1 << 20, size=m, dtype=np.uint32) >> rng.integers(0, 20, size=m).astype(np.uint32)).astype(np.uint32)
+    sym = rng.integers(0, 40, size=m, dtype=np.uint8)
+    init = np.full(256, n, dtype=np.uint32)
+    init[:40] = np.arange(40)
+    want = model.stream_encode("dark", n, init, dist, sym, 77)
+    # the frontier moves in 16 steps
+    ready = C.c_size_t(0)
+
+    def feeder():
+        for c in range(16):
+            time.sleep(0.002)
+            ready.value = m * (c + 1) // 16
+    t = threading.Thread(target=feeder)
+    t.start()
+    rc, got = _gated_encode(n, init, dist, sym, 77, ready, 5000, threads)
+    t.join()
+    assert rc == 0 and got == want
+    # the frontier stalls half way: every thread of the pipeline must come back
+    ready = C.c_size_t(m // 2)
+    t0 = time.perf_counter()
+    rc, _ = _gated_encode(n, init, dist, sym, 77, ready, 150, threads)
+    assert rc == _lib.DK_E_HIP and time.perf_counter() - t0 < 20
+    # the producer gives up
+    ready = C.c_size_t(m // 4)
+
+    def poisoner():
+        time.sleep(0.01)
+        ready.value = (1 << 64) - 1
+    t = threading.Thread(target=poisoner)
+    t.start()
+    rc, _ = _gated_encode(n, init, dist, sym, 77, ready, 5000, threads)
+    t.join()
+    assert rc == _lib.DK_E_HIP

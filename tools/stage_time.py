@@ -1,6 +1,6 @@
 """Times one device stage alone on the GPU box, per kernel slot, with and without HIP-event pairs around the launches:
 
-    python tools/stage_time.py sa  [N] [text|acgt|random]     suffix sort + BWT (dk_dev_bwt_forward)
+    python tools/stage_time.py sa  [N] [text|wordlike|acgt|random]     suffix sort + BWT (dk_dev_bwt_forward)
     python tools/stage_time.py dc  [N] [text|acgt|random]     distance coding (dk_dev_dc_encode); "text" = the BWT of the text block
     python tools/stage_time.py ibwt [N] [text|acgt|random]    inverse BWT (dk_dev_bwt_inverse) of the block's BWT
 
@@ -24,6 +24,8 @@ def make_input(kind, n):
     g.manual_seed(5)
     if kind == "text":
         return torch.from_numpy(datagen.wiki_like(n, 2)).cuda()
+    if kind == "wordlike":  # the bench workload wordlike_1e8 at n = 1e8
+        return torch.from_numpy(datagen.word_like(n, 5)).cuda()
     if kind == "acgt":
         return torch.from_numpy(np.frombuffer(b"ACGT", np.uint8)).cuda()[torch.randint(0, 4, (n,), device="cuda", generator=g)]
     return torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda", generator=g)

@@ -7,33 +7,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np, torch
 import dark_amd
 
-def zipf_text(n, seed=5, vocab=200_000, alpha=26):
-    rng = np.random.default_rng(seed)
-    lens = rng.integers(2, 11, size=vocab)
-    letters = (rng.integers(0, alpha, size=int(lens.sum())) + (97 if alpha <= 26 else 48)).astype(np.uint8)  # alpha > 128: codes of 8 bits, like real enwik8
-    offs = np.concatenate([[0], np.cumsum(lens)])
-    # Zipf ranks
-    nwords = n // 5
-    ranks = np.minimum(rng.zipf(1.15, size=nwords) - 1, vocab - 1)
-    wl = lens[ranks] + 1
-    total = int(wl.sum())
-    out = np.full(total, 32, dtype=np.uint8)
-    starts = np.concatenate([[0], np.cumsum(wl)[:-1]])
-    # fill word letters (vectorised by word length)
-    for L in range(2, 11):
-        sel = np.nonzero(lens[ranks] == L)[0]
-        if len(sel) == 0: continue
-        src = offs[ranks[sel]][:, None] + np.arange(L)[None, :]
-        dst = starts[sel][:, None] + np.arange(L)[None, :]
-        out[dst.reshape(-1)] = letters[src.reshape(-1)]
-    out = out[:n]
-    # sentence structure + 3 % copied segments
-    out[rng.integers(0, len(out), size=len(out) // 80)] = 10
-    budget = len(out) // 33
-    while budget > 0:
-        ln = int(rng.integers(64, 4097)); s = int(rng.integers(0, len(out) - ln)); d = int(rng.integers(0, len(out) - ln))
-        out[d:d + ln] = out[s:s + ln].copy(); budget -= ln
-    return out
+from dark_amd.datagen import word_like as zipf_text  # the bench workload wordlike_1e8 is zipf_text(100_000_000, alpha=180)
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
 alpha = int(sys.argv[2]) if len(sys.argv) > 2 else 26
