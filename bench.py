@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--gather", default="rccl", choices=("rccl", "host"),
                     help="how the final bitstreams reach rank 0 inside the timed region: RCCL over xGMI (north_star) or a host-side gloo gather; "
                          "the other one is timed beside it")
+    ap.add_argument("--no-rccl-selftest", action="store_true",
+                    help="one-rank runs without a launcher: skip the pass of the finished stream through init_process_group('nccl', world_size=1) + "
+                         "the RCCL gather code after the timed region")
     ap.add_argument("--node-gpus", type=int, default=0, help="GPUs of the node the per-rank CPU share is computed for (default: visible devices)")
     ap.add_argument("--stub-exchange", action="store_true",
                     help="CPU rehearsal of the multi-rank plumbing (launcher, process group, exchange, max-over-ranks timing) with backend gloo: "
@@ -152,6 +155,32 @@ def exchange_streams(torch, dist, stream_np, world, rank, dev, group):
         return [b[:l] for b, l in zip(bufs, lens)]
     dist.gather(pad, None, dst=0, **kw)
     return None
+
+
+def rccl_selftest(torch, dist, stream_np, dev):
+    """A plain one-GPU run (no launcher) never needs a process group; so that the RCCL leg of the N > 1 runs has executed on the box
+    that produced the line, the finished stream goes once more through exactly that code -- init_process_group("nccl") with the world
+    size the box has (1) and the device-buffer form of exchange_streams -- after the timed region, and the line says what happened."""
+    out = {"world_size": 1, "when": "after the timed region (the headline of a one-rank run has no exchange in it)"}
+    try:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        t0 = time.perf_counter()
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        got = exchange_streams(torch, dist, stream_np, 1, 0, dev, None)
+        torch.cuda.synchronize(dev)
+        out["rccl_init_and_first_ms"] = round(1e3 * (time.perf_counter() - t0), 1)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            got = exchange_streams(torch, dist, stream_np, 1, 0, dev, None)
+        torch.cuda.synchronize(dev)
+        out["rccl"] = round(1e3 * (time.perf_counter() - t0) / 3, 3)
+        out["rccl_ok"] = bool(len(got) == 1 and got[0].cpu().numpy().tobytes() == stream_np.tobytes())
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001 -- reported in the line, never fatal for the measurement above
+        out["rccl_ok"] = False
+        out["error"] = "%s: %s" % (type(e).__name__, e)
+    return out
 
 
 def stub_exchange(args, world, rank):
@@ -281,7 +310,10 @@ def main():
     import dark_amd
 
     host_group = None
-    if world > 1:
+    # under a launcher (torchrun sets RANK / WORLD_SIZE, also for one rank) the run is a distributed job at every N: process groups,
+    # barriers and the RCCL gather are the N > 1 code, executed with whatever world size the launcher gave
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
@@ -289,13 +321,13 @@ def main():
         host_group = dist.new_group(backend="gloo")  # the host-side alternative for the final gather
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if use_dist else 0)
 
     # One coding pipeline per rank needs one last-level-cache group per rank.  Every rank reports how many groups it could claim; the
     # smallest answer decides the thread form of ALL ranks, so that max-over-ranks is not decided by who loses the race for a group.
     from dark_amd import entropy as dk_entropy
     groups = [dk_entropy.l3_groups(4), dk_entropy.l3_groups(2)]
-    if world > 1:
+    if use_dist:
         gt = torch.tensor(groups, dtype=torch.int64)
         dist.all_reduce(gt, op=dist.ReduceOp.MIN, group=host_group)
         groups_min = [int(x) for x in gt]
@@ -322,14 +354,14 @@ def main():
     out_buf = np.empty(n + n // 2 + 4096, dtype=np.uint8)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
     def gather_streams(stream_np, how=None):
         """The final bitstreams reach rank 0: lengths first (all_gather), then the padded payloads (gather).
         rccl: through device buffers over xGMI (north_star); host: the stream never leaves host memory (gloo)."""
-        if world == 1:
+        if not use_dist:
             return [stream_np]
         return exchange_streams(torch, dist, stream_np, world, rank, dev if (how or args.gather) == "rccl" else None, host_group)
 
@@ -370,12 +402,12 @@ def main():
             clean_acc[k] = clean_acc.get(k, 0.0) + st[k] / clean_steps
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed_max = float(tmax.item())
     # every rank's view of its own timed steps, for rank 0's line: a rank that fell back to fewer coding threads shows here
     mine = rank_report(rank, args.steps, elapsed, stage_acc, threads_seen, groups_seen, groups, n, len(stream))
-    if world > 1:
+    if use_dist:
         reports = [None] * world
         dist.all_gather_object(reports, mine, group=host_group)
     else:
@@ -398,7 +430,7 @@ def main():
             barrier()
             ctx.set_profiling(False)
             dt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-            if world > 1:
+            if use_dist:
                 dist.all_reduce(dt, op=dist.ReduceOp.MAX)
             decode_mbps = world * n * args.steps / float(dt.item()) / 1e6
             roundtrip_ok = bool(torch.equal(d_out, d_in))
@@ -409,8 +441,8 @@ def main():
 
     # the two ways the final bitstreams can reach rank 0, timed on the stream just produced (the headline used args.gather)
     gather_ms = None
-    if world > 1:
-        gather_ms = {}
+    if use_dist:
+        gather_ms = {"world_size": world}
         for how in ("rccl", "host"):
             gather_streams(stream, how)
             barrier()
@@ -460,7 +492,7 @@ def main():
                 res = ctx.dev_batch_encode(args.model, d_blocks, [n] * B, args.pipeline_threads, outs)
                 barrier()
                 dtp = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device=dev)
-                if world > 1:
+                if use_dist:
                     dist.all_reduce(dtp, op=dist.ReduceOp.MAX)
                 secs.append(float(dtp.item()))
                 same = same and res[0].tobytes() == stream.tobytes()
@@ -477,7 +509,7 @@ def main():
                     ctx.dev_batch_decode(args.model, res, [n] * B, d_outs, args.pipeline_threads)
                     barrier()
                     dtd = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device=dev)
-                    if world > 1:
+                    if use_dist:
                         dist.all_reduce(dtd, op=dist.ReduceOp.MAX)
                     dsecs.append(float(dtd.item()))
                 pipelined["decode_MBps"] = round(world * B * n / sorted(dsecs)[len(dsecs) // 2] / 1e6, 1)
@@ -571,7 +603,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64 integer", "data": "real" if corpus_path else "synthetic",
             "config": {"workload": workload_name, "block_bytes": n, "model": args.model,
                        "blocks_per_gpu": 1, "parallelism": "block-per-gpu x%d" % world, "host_cpus_per_rank": share, "node_gpus": node_gpus,
-                       "gather": args.gather if world > 1 else "none"},
+                       "gather": args.gather if use_dist else "none"},
             "bwt_forward_MBps_per_gpu": round(n / (fwd_ms * 1e-3) / 1e6, 1),
             "device_forward_MBps_per_gpu": round(n / ((fwd_ms + clean_acc["ms_dc"]) * 1e-3) / 1e6, 1),
             "decode_MBps": None if decode_mbps is None else round(decode_mbps, 3),
@@ -644,8 +676,10 @@ def main():
             # parity at sample scale: the same prefix through the GPU path must give the identical coded stream
             gpu_sample = stream.tobytes() if len(sample) == n else ctx.dev_block_encode(args.model, d_in[:len(sample)], len(sample)).tobytes()
             result["cpu_baseline"]["gpu_stream_identical_on_sample"] = bool(gpu_sample == ref_stream)
+        if not use_dist and not args.no_rccl_selftest:
+            result["gather_ms"] = rccl_selftest(torch, dist, stream, dev)
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -52,6 +52,9 @@ def _build_one(force, verbose, tuning):
                 # the models, the sinks and the coder are small functions calling each other once per coded decision: with the
                 # default threshold clang leaves some of them out of line (measured on the GPU box: 22.5 -> 18.4 ns per distance, decode 42 -> 37)
                 extra += ["-mllvm", "-inline-threshold=20000"]
+                # the pipeline's loops are a few dozen instructions each and their speed moves by 2-3 % with where they happen to start
+                # (profiles/r04_entropy_ab.json: the same source 450.8 / 441.6 / 399.4 ms aligned against 456.6 / 454.9 / 407.4 ms)
+                extra += ["-falign-loops=32", "-falign-functions=64"]
             if special:
                 extra += ["-DDK_TUNING"]
             cmd = [HIPCC] + CXXFLAGS + extra + ["-c", sp, "-o", op]

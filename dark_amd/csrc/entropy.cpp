@@ -1086,9 +1086,12 @@ struct DarkExponentSide {
     DarkModel &m;
     bool encode(uint32_t dist, uint8_t symbol, USink &e) { return m.encode_exponent(dist, symbol, e); }
 };
+// (only the three MODELLED mantissa bits: the flat tail below them goes through a model that never learns, dark.rs:225-227 -- no state, so
+// the merger makes those events itself.  With the tail on this thread it was the pipeline's slowest stage: it never waited, the other
+// three did; profiles/r04_entropy_ab.json)
 struct DarkMantissaSide {
     DarkModel &m;
-    bool encode(uint32_t dist, uint8_t, USink &e) { return m.encode_mantissa_modelled(dist, e) && DarkModel::encode_mantissa_flat(dist, e); }
+    bool encode(uint32_t dist, uint8_t, USink &e) { return m.encode_mantissa_modelled(dist, e); }
 };
 struct DarkMergeSide {  // the order of dark.rs:180-232: table decision, unary extension, mantissa bits
     UReader &exponent;
@@ -1116,9 +1119,26 @@ struct DarkMergeSide {  // the order of dark.rs:180-232: table decision, unary e
         }
         return true;
     }
+    // the mantissa bits below the three modelled ones, most significant first: a decision between two halves of 4096 each (the
+    // never-updated model of dark.rs:225-227 stays at its initial zero = 2048), four events at a time like move()
+    static inline void flat_tail(USink &to, uint32_t v, unsigned log) {
+        for (unsigned left = log - 4; left;) {  // bits left - 1 .. 0 of v are still to go
+            UEvent *out = to.tail(4);
+            const unsigned c = left < 4 ? left : 4;
+            for (unsigned j = 0; j < 4; ++j) {  // (what is written beyond c is overwritten by the next events)
+                const uint32_t one = (v >> ((left - 1 - j) & 31u)) & 1u;
+                out[j] = UEvent{1ull << 52, one << 11, 2048u + (one << 11)};
+            }
+            to.advance(c);
+            left -= c;
+        }
+    }
     bool encode(uint32_t dist, uint8_t, USink &e) {
         if (dist >= 0x7FFFFFFFu) return false;
-        return move(exponent, e, 1 + DarkModel::exponent_bits(dist)) && move(mantissa, e, bit_length(dist + 1) - 1);
+        const unsigned log = bit_length(dist + 1);
+        if (!move(exponent, e, 1 + DarkModel::exponent_bits(dist)) || !move(mantissa, e, DarkModel::modelled_mantissa_bits(dist))) return false;
+        if (log > 4) flat_tail(e, dist + 1, log);
+        return true;
     }
 };
 
