@@ -38,8 +38,9 @@ def parse():
     ap.add_argument("--n", type=int, default=0, help="override the block size (debug)")
     ap.add_argument("--model", default="dark")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=32_000_000,
-                    help="bytes of the block (a prefix) the CPU oracle is timed on, --cpu-runs times, median reported (default 32 MB x 3: about 15 s of one core)")
+    ap.add_argument("--cpu-sample", type=int, default=0,
+                    help="bytes of the block (a prefix) the CPU oracle is timed on, --cpu-runs times, median reported; 0 (default) = the whole block, "
+                         "SURVEY 8(d) 'same inputs': about 12 s of one core per run at 1e8 bytes")
     ap.add_argument("--cpu-runs", type=int, default=3)
     ap.add_argument("--corpus", default="",
                     help="a real file instead of the synthetic stand-in (book1, enwik8, enwik9 ...): rank r codes block r of the file cut into blocks of the "
@@ -591,6 +592,9 @@ def main():
             fwd_ms_prof = per["ms_sa"] + per["ms_bwt"]  # the timed steps themselves (with the HIP-event pairs of the per-kernel times)
             fwd_roofline = {"B_fwd_formula_bytes": b_formula, "rounds": R, "passes_P": P, "measured_hbm_bytes": round(measured),
                             "t_fwd_ms": round(fwd_ms, 3), "achieved_GBs": round(ach, 1), "frac_of_8TBs": round(ach / HBM_PEAK_GBS, 4),
+                            # the same on the counters as rocprofv3 printed them (no x2 on FETCH_SIZE for streaming kernels: the guide's correction made visible)
+                            "frac_raw_counters": None if not all("raw_hbm_bytes_per_launch" in v for v in fwd_kernels.values()) else round(
+                                min(b_formula, sum(v["raw_hbm_bytes_per_launch"] * v["launches_per_step"] for v in fwd_kernels.values())) / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             "useful_hbm_bytes": round(useful), "achieved_useful_GBs": round(ach_u, 1),
                             "frac_of_8TBs_useful": round(ach_u / HBM_PEAK_GBS, 4),
                             "t_fwd_ms_timed_steps": round(fwd_ms_prof, 3),
@@ -658,7 +662,7 @@ def main():
             result["decode_kernel_ms_per_step"] = {kk: round(v["ms"] / k, 3) for kk, v in sorted(dstats["kernels"].items(), key=lambda x: -x[1]["ms"])}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import orc  # the checker, timed as the CPU baseline (never the thing measured above)
-            sample = block[:min(n, args.cpu_sample)]
+            sample = block[:min(n, args.cpu_sample)] if args.cpu_sample else block
             runs, ref_stream, stages = [], None, None
             for _ in range(max(1, args.cpu_runs)):
                 tc = time.perf_counter()

@@ -21,7 +21,11 @@ class Stats(C.Structure):
                 ("rounds", C.c_uint32), ("sort_passes", C.c_uint32), ("sorted_elements", C.c_uint64),
                 ("dc_runs", C.c_uint64), ("entropy_threads", C.c_uint32), ("entropy_l3_group", C.c_int32),
                 ("kernel_launches", C.c_uint32 * NUM_KERNEL_SLOTS), ("kernel_ms", C.c_double * NUM_KERNEL_SLOTS),
-                ("kernel_bytes", C.c_double * NUM_KERNEL_SLOTS)]
+                ("kernel_bytes", C.c_double * NUM_KERNEL_SLOTS), ("sa_route", C.c_uint32), ("reserved_", C.c_uint32),
+                ("ws_peak_bytes", C.c_uint64), ("ws_size_bytes", C.c_uint64)]
+ROUTES = {"short_prefix": 0x1, "narrow_keys": 0x2, "text_round": 0x4, "isa_windows": 0x8, "isa_marked": 0x10, "isa_buckets": 0x20,
+          "general_round": 0x40, "big_groups": 0x80, "inplace_rounds": 0x100, "pair_chains": 0x200, "lfirst": 0x400,
+          "lfirst_big_round": 0x800, "lfirst_deep": 0x1000, "lfirst_fallback": 0x2000}
 
 
 # every symbol include/dark_amd.h declares: name -> (restype, argtypes)

@@ -249,7 +249,7 @@ class Context:
         self._ck(self._lib.dk_get_stats(self._h, C.byref(st)))
         out = {k: getattr(st, k) for k in ("ms_h2d", "ms_sa", "ms_bwt", "ms_dc", "ms_d2h", "ms_entropy", "ms_ibwt",
                                            "ms_total", "rounds", "sort_passes", "sorted_elements", "dc_runs",
-                                           "entropy_threads", "entropy_l3_group")}
+                                           "entropy_threads", "entropy_l3_group", "ws_peak_bytes", "ws_size_bytes")}
         kernels = {}
         for i in range(_lib.NUM_KERNEL_SLOTS):
             name = self._lib.dk_kernel_name(i)
@@ -257,6 +257,7 @@ class Context:
                 kernels[name.decode()] = dict(launches=int(st.kernel_launches[i]), ms=float(st.kernel_ms[i]),
                                               bytes=float(st.kernel_bytes[i]))
         out["kernels"] = kernels
+        out["routes"] = {name for name, bit in _lib.ROUTES.items() if st.sa_route & bit}  # which ways the last suffix sort took
         return out
 
     def dbg_sort_pairs(self, keys, vals, begin_bit=0, end_bit=64):

@@ -47,14 +47,18 @@ size_t workspace_bytes(size_t max_n) {
     //   L                                           n
     //   SA                                         4 n
     //   suffix sort: keys x3 24 n, suffix lists x3 12 n, rank 4 n, slot positions x2 8 n, group ids x2 8 n,
-    //                gstart + bigstart 4 n, symbols in front x2 2 n                                  = 62 n
-    //   radix sort inside it: per-tile digit tables n / 4 (256 counters per 4096 pairs), digit plane n (optional, >= 2^28 pairs:
-    //                ws_try_alloc -- the sort runs without it when it does not fit)
-    //   rerank / classification aggregates         < n / 64
-    // = 69.3 n; every allocation is rounded up to 256 bytes (about forty of them: < 16 KiB).  The DC arrays (10 n) and the inverse
+    //                gstart + bigidx 4 n, big-group offsets n / 8, symbols in front x2 2 n            = 62.1 n
+    //   on top of that, one of (never two at a time: each is released before the next is taken)
+    //     radix sort: per-tile digit tables n / 4 (256 counters per 4096 pairs) + digit plane n (optional, from 2^26 pairs:
+    //                 ws_try_alloc -- the sort runs without it when it does not fit)                  = 1.25 n
+    //     rerank:     one flag byte per slot n + tile aggregates n / 64 (L-first: + n / 128)          = 1.03 n
+    //     pair chains: one verdict byte per record, at most n / 2
+    //     L-first:    the list of deep groups, 16 MiB
+    // = 69.4 n + 16 MiB; every allocation is rounded up to 256 bytes (about forty of them: < 16 KiB).  The DC arrays (10 n) and the inverse
     // BWT's successor table (8 n) are allocated after the sort's temporaries are released and take their place.
-    const size_t sort_temporaries = 62 * max_n, io = 6 * max_n, tables = max_n / 4 + max_n / 64, plane = max_n;
-    return sort_temporaries + io + tables + plane + max_n / 2 /* headroom */ + (48u << 20);
+    // tests/test_gpu_parity.py::test_workspace_accounting checks peak <= size on contexts sized exactly to their block.
+    const size_t sort_temporaries = 62 * max_n + max_n / 8, io = 6 * max_n, on_top = max_n / 4 + max_n;
+    return sort_temporaries + io + on_top + max_n / 4 /* headroom */ + (64u << 20);
 }
 struct ScopedCall {
     dk_ctx *c;
@@ -910,6 +914,8 @@ int dk_stats_reset(dk_ctx *ctx) {
 int dk_get_stats(const dk_ctx *ctx, dk_stats *out) {
     if (!ctx || !out) return DK_E_ARG;
     *out = ctx->stats;
+    out->ws_peak_bytes = ctx->ws_peak;
+    out->ws_size_bytes = ctx->ws_size;
     return DK_OK;
 }
 const char *dk_kernel_name(int slot) { return kernel_slot_name(slot); }

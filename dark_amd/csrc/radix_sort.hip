@@ -820,10 +820,10 @@ static int inverse_permutation_windows(dk_ctx *ctx, const uint32_t *sa, size_t n
     }
     {
         LaunchScope ls(ctx, K_ISA_ASSEMBLE, 12.0 * n);
-        static const bool lds_ok = [] {  // a workgroup may declare more than the default 64 KiB of dynamic LDS only after this
-            return hipFuncSetAttribute(reinterpret_cast<const void *>(k_isa_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, 4 << ISA_WBITS) == hipSuccess;
-        }();
-        if (!lds_ok) return ctx->fail(DK_E_HIP, "k_isa_assemble: cannot reserve %d bytes of LDS", 4 << ISA_WBITS);
+        // a workgroup may declare more than the default 64 KiB of dynamic LDS only after this; the attribute belongs to the function ON THE
+        // CURRENT DEVICE (a process may hold contexts on several GPUs), so it is set before every launch -- it costs a table lookup
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_isa_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, 4 << ISA_WBITS) != hipSuccess)
+            return ctx->fail(DK_E_HIP, "k_isa_assemble: cannot reserve %d bytes of LDS", 4 << ISA_WBITS);
         k_isa_assemble<<<dim3(nwin), dim3(ISA_BLOCK), sizeof(uint32_t) << wbits, st>>>(by_window, n, wbits, rank);
     }
     DK_HIP(ctx, hipGetLastError());

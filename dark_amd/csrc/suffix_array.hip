@@ -670,10 +670,10 @@ constexpr int PL_MAX = 1 << PL_BITS;  // in-place (plateau) rounds need every gr
 constexpr int BG_IPT = 16;
 constexpr int BG_TILE = 256 * BG_IPT;
 
-__device__ __forceinline__ uint32_t big_size(const uint32_t *__restrict__ gstart, size_t g, size_t groups) {
+__device__ __forceinline__ uint32_t big_size(const uint32_t *__restrict__ gstart, size_t g, size_t groups, uint32_t ls_max) {
     if (g >= groups) return 0;
     const uint32_t sz = gstart[g + 1] - gstart[g];
-    return sz > static_cast<uint32_t>(LS_MAX) ? sz : 0u;
+    return sz > ls_max ? sz : 0u;
 }
 // `groups` is read from mail[1] on the device: the host does not know it yet when these kernels are enqueued.  The grid is fixed
 // (BG_GRID workgroups); every workgroup takes a contiguous stretch of tiles of groups, so that `part` has BG_GRID entries whatever n.
@@ -685,7 +685,7 @@ __device__ __forceinline__ void big_stretch(size_t groups, size_t *t0, size_t *t
     *t1 = *t0 + per < ntiles ? *t0 + per : ntiles;
 }
 __global__ __launch_bounds__(256) void k_big_reduce(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ mail,
-                                                     uint2 *__restrict__ part) {
+                                                     uint2 *__restrict__ part, uint32_t ls_max) {
     __shared__ uint32_t s_w[2][RR_WAVES];
     const size_t groups = mail[1];
     size_t t0, t1;
@@ -700,8 +700,8 @@ __global__ __launch_bounds__(256) void k_big_reduce(const uint32_t *__restrict__
             const uint32_t next = gstart[g0 + j + 1];
             const uint32_t sz = next - prev;
             prev = next;
-            sum += sz > static_cast<uint32_t>(LS_MAX) ? sz : 0u;
-            cnt += sz > static_cast<uint32_t>(LS_MAX) ? 1u : 0u;
+            sum += sz > ls_max ? sz : 0u;
+            cnt += sz > ls_max ? 1u : 0u;
             medium += sz > static_cast<uint32_t>(PL_MAX) ? sz : 0u;
         }
     }
@@ -723,7 +723,8 @@ __global__ __launch_bounds__(BG_GRID) void k_big_spine(uint2 *__restrict__ part,
     if (threadIdx.x == 0) { mail[2] = total; mail[4] = total_cnt; }
 }
 __global__ __launch_bounds__(256) void k_big_apply(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ mail,
-                                                    const uint2 *__restrict__ part, uint32_t *__restrict__ bigidx, uint32_t *__restrict__ bigoff) {
+                                                    const uint2 *__restrict__ part, uint32_t *__restrict__ bigidx, uint32_t *__restrict__ bigoff,
+                                                    uint32_t ls_max) {
     __shared__ uint32_t s_tmp[RR_WAVES + 1];
     const size_t groups = mail[1];
     size_t t0, t1;
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(256) void k_big_apply(const uint32_t *__restrict__ 
         const size_t g0 = t * BG_TILE + static_cast<size_t>(threadIdx.x) * BG_IPT;
         uint32_t v[BG_IPT], sum = 0, cnt = 0;
 #pragma unroll
-        for (int j = 0; j < BG_IPT; ++j) { v[j] = big_size(gstart, g0 + j, groups); sum += v[j]; cnt += v[j] ? 1u : 0u; }
+        for (int j = 0; j < BG_IPT; ++j) { v[j] = big_size(gstart, g0 + j, groups, ls_max); sum += v[j]; cnt += v[j] ? 1u : 0u; }
         uint32_t tile_sum, tile_cnt;
         uint32_t run = base.x + block_excl_sum<RR_WAVES>(sum, s_tmp, &tile_sum);
         uint32_t idx = base.y + block_excl_sum<RR_WAVES>(cnt, s_tmp, &tile_cnt);
@@ -1283,7 +1284,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_plateau_compact(const uint32_t *__
 // enqueue the classification of the groups rerank() just produced and read back (active, groups, big slots, slots in groups > PL_MAX,
 // big groups)
 int classify_and_read(dk_ctx *ctx, size_t max_groups, uint32_t *gstart, uint32_t *bigidx, uint32_t *bigoff, size_t *active, size_t *groups,
-                      size_t *nbig, size_t *nmedium, size_t *nbiggroups) {
+                      size_t *nbig, size_t *nmedium, size_t *nbiggroups, uint32_t ls_max = LS_MAX) {
     hipStream_t st = ctx->stream;
     const size_t mark = ctx->ws_mark();
     (void)max_groups;
@@ -1292,9 +1293,9 @@ int classify_and_read(dk_ctx *ctx, size_t max_groups, uint32_t *gstart, uint32_t
     DK_HIP(ctx, hipMemsetAsync(ctx->d_mail + 3, 0, sizeof(uint32_t), st));
     {
         LaunchScope ls(ctx, K_BIG_CLASSIFY, 8.0 * max_groups);
-        k_big_reduce<<<dim3(BG_GRID), dim3(256), 0, st>>>(gstart, ctx->d_mail, part);
+        k_big_reduce<<<dim3(BG_GRID), dim3(256), 0, st>>>(gstart, ctx->d_mail, part, ls_max);
         k_big_spine<<<dim3(1), dim3(BG_GRID), 0, st>>>(part, ctx->d_mail);
-        k_big_apply<<<dim3(BG_GRID), dim3(256), 0, st>>>(gstart, ctx->d_mail, part, bigidx, bigoff);
+        k_big_apply<<<dim3(BG_GRID), dim3(256), 0, st>>>(gstart, ctx->d_mail, part, bigidx, bigoff, ls_max);
     }
     DK_HIP(ctx, hipGetLastError());
     DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -1308,15 +1309,27 @@ int classify_and_read(dk_ctx *ctx, size_t max_groups, uint32_t *gstart, uint32_t
     return DK_OK;
 }
 
+#include "lfirst.inc"
+
+int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_sa, uint8_t *d_bwt, uint32_t *d_origin, bool *bwt_written, bool allow_lfirst);
+
 }  // namespace
 
 int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_sa, uint8_t *d_bwt, uint32_t *d_origin, bool *bwt_written) {
+    return suffix_array_impl(ctx, d_text, n, d_sa, d_bwt, d_origin, bwt_written, true);
+}
+
+namespace {
+
+int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_sa, uint8_t *d_bwt, uint32_t *d_origin, bool *bwt_written, bool allow_lfirst) {
     if (bwt_written) *bwt_written = false;
     if (n == 0 || n > 0x7FFFFFFEull) return ctx->fail(DK_E_ARG, "suffix_array: n out of range");
     hipStream_t st = ctx->stream;
     ctx->stats.rounds = 0;
     ctx->stats.sort_passes = 0;
     ctx->stats.sorted_elements = 0;
+    ctx->stats.sa_route = allow_lfirst ? 0u : static_cast<uint32_t>(DK_ROUTE_LFIRST_FALLBACK);
+    uint32_t &route = ctx->stats.sa_route;
     const size_t mark = ctx->ws_mark();
 
     // 1. alphabet
@@ -1350,7 +1363,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     uint32_t *pos = ctx->ws_alloc<uint32_t>(n), *pos_alt = ctx->ws_alloc<uint32_t>(n);
     uint32_t *gid = ctx->ws_alloc<uint32_t>(n), *gid_alt = ctx->ws_alloc<uint32_t>(n);
     uint32_t *gstart = ctx->ws_alloc<uint32_t>(n / 2 + 2), *bigidx = ctx->ws_alloc<uint32_t>(n / 2 + 2);
-    uint32_t *bigoff = ctx->ws_alloc<uint32_t>(n / LS_MAX + 2);  // one entry per big group (more than LS_MAX members each)
+    uint32_t *bigoff = ctx->ws_alloc<uint32_t>(n / 32 + 2);  // one entry per big group (more than LS_MAX members each; the L-first path may draw the line at 32)
     uint8_t *d_code = reinterpret_cast<uint8_t *>(ctx->d_mail + 512);
     if (!keys || !keys_alt || !keys_3 || !vals || !vals_alt || !vals_3 || !rank || !pos || !pos_alt || !gid || !gid_alt ||
         !gstart || !bigidx || !bigoff)
@@ -1363,6 +1376,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     //    the five-pass sort whose narrow keys need the bucket starts)
     const int prefix_mode = DK_KNOB("DK_PREFIX", 1);
     int spk_sort = spk;
+    double probe_big_share = 0.0;
     if (prefix_mode != 0 && (n >= (1u << 22) || prefix_mode >= 2)) {
         ProbeCands cands{0, {0, 0, 0, 0}};
         for (int passes = 4; passes <= 7 && cands.count < PP_MAX_CAND; ++passes) {
@@ -1394,6 +1408,9 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
             const uint32_t max_dups = static_cast<uint32_t>(DK_KNOB("DK_PROBE_DUPS", 4));
             for (int c = 0; c < cands.count; ++c)
                 if (ctx->h_mail[300 + c] <= max_dups) { spk_sort = cands.sym[c]; break; }
+            // the deepest candidate is (about) the key of the initial sort: a sample of 10 sqrt(n) suffixes meets an equal one there about as
+            // often as a suffix sits in a group of more than sqrt(n) / 10 members -- the share of the big groups
+            probe_big_share = static_cast<double>(ctx->h_mail[300 + cands.count - 1]) / m;
             if (trace)
                 fprintf(stderr, "[dk] prefix probe: %u samples, equal pairs at %d/%d/%d/%d symbols: %u %u %u %u -> sort %d of %d symbols\n", m,
                         cands.sym[0], cands.sym[1], cands.sym[2], cands.sym[3], ctx->h_mail[300], ctx->h_mail[301], ctx->h_mail[302],
@@ -1437,6 +1454,31 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
         DK_TRY(sort_pairs(ctx, keys, keys_alt, vals, vals_alt, n, key_shift, bits * spk_sort + key_shift, &tk, &fin));
     }
 
+    if (short_prefix) route |= DK_ROUTE_SHORT_PREFIX;
+    if (narrow_keys) route |= DK_ROUTE_NARROW_KEYS;
+    // 3b. A caller that wants L, not the suffix array: only the groups with different symbols in front are refined, from the text alone
+    //     (lfirst.inc).  DK_LFIRST: 0 = never, 1 = blocks of at least 2^16 bytes (default), 2 = always (test hook).
+    const int lf_mode = DK_KNOB("DK_LFIRST", 1);
+    // Not where the probe saw a quarter of its sample in big groups (lfirst_path would find the same after a rerank, see there), and not
+    // behind a shortened key: next to nothing survives such a sort, and the uniformity test costs the first rerank more than it saves
+    // (2^30 random bytes: reduce 2.3 against 1.1 ms, nothing else differs; 2^28 {A,C,G,T}: 8.63 against 8.56 ms).
+    if (carry_bwt && allow_lfirst && lf_mode != 0 && (lf_mode == 2 || (n >= (1u << 16) && probe_big_share <= 0.25 && !short_prefix))) {
+        const LfBuffers b{keys_alt, keys_3, vals_3, vals, rank, sym_alt, vals_alt, pos, gid, sym, gstart, bigidx, bigoff};
+        bool done = false, pristine = true;
+        route |= DK_ROUTE_LFIRST;
+        DK_TRY(lfirst_path(ctx, d_text, n, keys, key_shift, narrow_keys ? d_starts : nullptr, d_sa, d_bwt, d_origin, b, static_cast<uint32_t>(spk_sort), trace, lf_mode == 2, &done, &pristine));
+        if (done) {
+            ctx->ws_release(mark);
+            *bwt_written = true;
+            return DK_OK;
+        }
+        route = (route & ~static_cast<uint32_t>(DK_ROUTE_LFIRST | DK_ROUTE_LFIRST_BIG_ROUND | DK_ROUTE_LFIRST_DEEP)) | DK_ROUTE_LFIRST_FALLBACK;
+        if (!pristine) {  // it gave up half way (L has been written to): the suffix-array path, from the start
+            ctx->ws_release(mark);
+            return suffix_array_impl(ctx, d_text, n, d_sa, d_bwt, d_origin, bwt_written, false);
+        }
+    }
+
     // 4. first rerank (slots are SA positions).  No rank array yet: the suffixes that survive the initial sort are first extended from
     //    the text (5a), which needs no ranks, and the rank array is built once, late, for whatever survives that (5b) -- one inverse
     //    permutation for the whole sort instead of one here plus tens of millions of random rank stores in the next round.
@@ -1473,6 +1515,8 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
             kbits = kb = static_cast<int>(ceil_log2_u64(static_cast<uint64_t>(n) + h_eff));
         }
         const TextSource ts{d_text, d_code, raw_text ? 0 : bits, tsym};
+        route |= tsym > 0 ? DK_ROUTE_TEXT_ROUND : DK_ROUTE_GENERAL_ROUND;
+        if (nbig > 0) route |= DK_ROUTE_BIG_GROUPS;
         const int big_carry = carry_bwt && kb + bsbits + 8 <= 64 ? 1 : 0;  // the big list's keys have room for the symbol in front
         uint32_t *bslot = pos_alt;  // written by the rerank at the end of the round only: free until k_big_back has read it
         {
@@ -1535,6 +1579,8 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
         // (worth it from a quarter of all suffixes active: the marked form costs the first split 0.17 ms per 1e8 suffixes, the second pass
         // it replaces 0.14 ms per 1e7 active ones)
         const bool marked = inverse_through_windows(n) && active * 4 > n;
+        route |= marked ? DK_ROUTE_ISA_MARKED : 0u;
+        route |= inverse_through_windows(n) ? DK_ROUTE_ISA_WINDOWS : DK_ROUTE_ISA_BUCKETS;
         uint32_t *head_pos = marked ? pos_alt : nullptr;
         {
             LaunchScope ls(ctx, K_PLACE_ACTIVE, (marked ? 28.0 : 12.0) * active);
@@ -1559,6 +1605,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     // ... then in place (k_plateau_sort): one sort kernel + one rank kernel per round, the live count read back one round late
     if (active > 0) {
         size_t slots = active;
+        route |= DK_ROUTE_INPLACE_ROUNDS;
         uint32_t *idx_a = vals, *idx_b = vals_alt;
         uint32_t *meta_a = gid, *meta_b = gid_alt;
         uint8_t *sym_a = sym, *sym_b = sym_alt;
@@ -1586,6 +1633,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
             const uint32_t m = ctx->h_mail[6];
             if (trace) fprintf(stderr, "[dk] pair chains: %u groups of two among %zu slots\n", m, slots);
             if (m > 0) {
+                route |= DK_ROUTE_PAIR_CHAINS;
                 DK_TRY(sort_pairs(ctx, rec_key, rec_key_alt, rec_slot, rec_slot_alt, m, 32, 32 + static_cast<int>(ceil_log2_u64(n))));
                 const size_t mark2 = ctx->ws_mark();
                 const uint32_t ntiles = static_cast<uint32_t>(div_up(m, CH_TILE));
@@ -1679,5 +1727,7 @@ int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *
     ctx->ws_release(mark);
     return DK_OK;
 }
+
+}  // namespace
 
 }  // namespace dk

@@ -128,7 +128,8 @@ int dk_dev_batch_encode(dk_ctx *ctx, int model_id, size_t count, const uint8_t *
  * frees the batch and returns the first failure.  Between begin and finish the context serves this batch only: every other entry point
  * returns DK_E_ARG, a second begin included.  A failed push leaves the batch open (earlier blocks are still being coded into the
  * caller's `out` / `out_len`): the caller must still call finish before it frees those buffers.  dk_ctx_destroy finishes a batch that
- * was left open, so the coding threads never outlive the staging memory they read. */
+ * was left open, so the coding threads never outlive the staging memory they read -- and with that the dk_batch handle is GONE: after
+ * dk_ctx_destroy it must not be passed to dk_batch_finish (or anything else) any more; the result of that implicit finish is dropped. */
 typedef struct dk_batch dk_batch;
 int dk_batch_begin(dk_ctx *ctx, int model_id, int host_threads, dk_batch **out);
 int dk_batch_push(dk_batch *batch, const uint8_t *d_in, size_t n, uint8_t *out, size_t out_cap, size_t *out_len);
@@ -195,7 +196,25 @@ typedef struct dk_stats {
     uint32_t kernel_launches[DK_NUM_KERNEL_SLOTS];
     double kernel_ms[DK_NUM_KERNEL_SLOTS];
     double kernel_bytes[DK_NUM_KERNEL_SLOTS]; /* algorithmic bytes summed over launches */
+    uint32_t sa_route;        /* DK_ROUTE_* bits: which ways through the suffix sort the last call took (tests assert the route they are named after) */
+    uint32_t reserved_;
+    uint64_t ws_peak_bytes;   /* most the context's device workspace has held at once since dk_ctx_create ... */
+    uint64_t ws_size_bytes;   /* ... and its size (about 69.4 x the capacity + 64 MiB) */
 } dk_stats;
+#define DK_ROUTE_SHORT_PREFIX 0x1u      /* the prefix probe shortened the initial sort's key */
+#define DK_ROUTE_NARROW_KEYS 0x2u       /* ... and its last pass left 32-bit keys */
+#define DK_ROUTE_TEXT_ROUND 0x4u        /* a text-extension round ran */
+#define DK_ROUTE_ISA_WINDOWS 0x8u       /* rank array through LDS windows */
+#define DK_ROUTE_ISA_MARKED 0x10u       /* ... with the active suffixes' head positions handed over by marked SA entries */
+#define DK_ROUTE_ISA_BUCKETS 0x20u      /* rank array by the bucketed store (blocks above 2^27 suffixes) */
+#define DK_ROUTE_GENERAL_ROUND 0x40u    /* a doubling round in its general form ran */
+#define DK_ROUTE_BIG_GROUPS 0x80u       /* ... with groups of more than 1024 members through the global sort */
+#define DK_ROUTE_INPLACE_ROUNDS 0x100u  /* in-place (plateau) rounds ran */
+#define DK_ROUTE_PAIR_CHAINS 0x200u     /* ... after pair chains settled groups of two */
+#define DK_ROUTE_LFIRST 0x400u          /* BWT callers: only groups with different symbols in front were refined (no suffix array) */
+#define DK_ROUTE_LFIRST_BIG_ROUND 0x800u  /* ... with at least one global-sort round of big groups */
+#define DK_ROUTE_LFIRST_DEEP 0x1000u    /* ... and groups that went the way of long repeats (common extension measured directly) */
+#define DK_ROUTE_LFIRST_FALLBACK 0x2000u  /* the L-first path gave up (giant groups / over-long common extensions): suffix-array path from the start */
 /* enable (1) / disable (0) HIP-event bracketing of every kernel launch on the context's stream */
 int dk_set_profiling(dk_ctx *ctx, int enabled);
 int dk_stats_reset(dk_ctx *ctx);

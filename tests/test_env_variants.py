@@ -147,7 +147,8 @@ def test_entropy_error_paths_return_codes(threads):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"DK_XCD": "0"}, {"DK_DIGIT_PLANE": "1"}, {"DK_PLATEAU": "0"}, {"DK_BWT_CARRY": "0"},
-                                 {"DK_PLATEAU": "0", "DK_BWT_CARRY": "0"}, {"DK_PAIR_CHAINS": "0"}, {"DK_PAIR_CHAINS": "1", "DK_BWT_CARRY": "0"}])
+                                 {"DK_PLATEAU": "0", "DK_BWT_CARRY": "0"}, {"DK_PAIR_CHAINS": "0"}, {"DK_PAIR_CHAINS": "1", "DK_BWT_CARRY": "0"},
+                                 {"DK_LFIRST": "0"}, {"DK_LFIRST": "2"}, {"DK_LFIRST": "2", "DK_LF_MAX": "32"}])
 def test_gpu_variants_match_oracle(env):
     _run(GPU_SNIPPET, env, tuning=True)
 
@@ -156,3 +157,10 @@ def test_gpu_variants_match_oracle(env):
 @pytest.mark.parametrize("mode", ["0", "1", "2", "3"])
 def test_gpu_prefix_paths_match_oracle(mode):
     _run(PREFIX_SNIPPET, {"DK_PREFIX": mode, "DK_TRACE": "1"}, tuning=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["2", "3"])
+def test_gpu_prefix_paths_with_lfirst_forced(mode):
+    """the L-first BWT path behind shortened (and narrow) keys, which the product never takes (csrc/suffix_array.hip: nothing survives such a sort)"""
+    _run(PREFIX_SNIPPET, {"DK_PREFIX": mode, "DK_LFIRST": "2"}, tuning=True)

@@ -59,15 +59,23 @@ def test_five_megabyte_blocks(orc):
     n = 5_000_011
     cases = [datagen.wiki_like(n, 7), datagen.acgt(n, 8), datagen.random_bytes(n, 9), np.frombuffer(b"ab" * (n // 2) + b"a", np.uint8),
              np.concatenate([datagen.wiki_like(n // 2, 10)] * 2)]
+    # what each case must have gone through: (suffix array call, BWT call)
+    routes = [({"isa_windows", "text_round", "inplace_rounds", "pair_chains"}, {"lfirst", "lfirst_deep"}),   # text: long repeats end as pair chains / deep groups
+              ({"short_prefix", "narrow_keys", "text_round"}, {"short_prefix", "narrow_keys"}),              # {A,C,G,T}: the probe shortens the key
+              ({"short_prefix", "narrow_keys"}, {"short_prefix", "narrow_keys"}),                            # random bytes
+              ({"isa_windows", "isa_marked", "general_round", "big_groups"}, {"general_round"}),              # period 2: giant groups
+              ({"isa_windows", "inplace_rounds"}, {"lfirst", "lfirst_deep"})]                                 # two identical halves
     with dark_amd.Context(n) as c:
-        for t in cases:
+        for t, (sa_route, bwt_route) in zip(cases, routes):
             t = np.ascontiguousarray(t)
             want_sa = orc.sa_sais(t)
             got = c.suffix_array(t)
             assert first_diff(got, want_sa) is None, first_diff(got, want_sa)
+            assert sa_route <= c.stats()["routes"] and "lfirst" not in c.stats()["routes"], (sa_route, c.stats()["routes"])
             want_bwt, want_origin = orc.bwt_forward(t, want_sa)
             bwt, origin = c.bwt_forward(t)
             assert origin == want_origin and first_diff(bwt, want_bwt) is None
+            assert bwt_route <= c.stats()["routes"], (bwt_route, c.stats()["routes"])
     del rng
 
 
@@ -109,7 +117,11 @@ def test_word_like_text(orc):
     with dark_amd.Context(len(t)) as c:
         want = orc.sa_sais(t)
         assert first_diff(c.suffix_array(t), want) is None
+        # the route this test is named after (a threshold change must not turn it into a duplicate of another test)
+        assert {"isa_windows", "isa_marked", "general_round", "big_groups"} <= c.stats()["routes"], c.stats()["routes"]
+        assert "text_round" not in c.stats()["routes"]  # most of what is active sits in big groups: straight to the ranks
         bwt, origin = c.bwt_forward(t)
+        assert "lfirst" not in c.stats()["routes"]  # big groups hold most of what is live: the BWT goes the suffix-array way too
         wb, wo = orc.bwt_forward(t, want)
         assert origin == wo and first_diff(bwt, wb) is None
         assert first_diff(c.bwt_inverse(bwt, origin), t) is None
@@ -428,6 +440,7 @@ def test_sizes_around_2p22(ctx, orc):
         sa = ctx.suffix_array(t)
         want = orc.sa_sais(t)
         assert first_diff(sa, want) is None, (n, first_diff(sa, want))
+        assert "isa_windows" in ctx.stats()["routes"], ctx.stats()["routes"]
 
 
 def test_batch_encode_matches_single(ctx, orc):
@@ -490,3 +503,60 @@ def test_dc_path_mixtures(ctx, orc):
             assert first_diff(got[key], want[key]) is None, (k, "dc." + key, len(L), first_diff(got[key], want[key]))
         out, used = orc.dc_decode(got["init"], got["d"], len(L))
         assert used == len(got["d"]) and first_diff(out, L) is None, (k, "dc round trip")
+
+
+def test_lfirst_bwt_without_the_suffix_array(orc):
+    """dk_bwt_forward on text: only groups of suffixes with different symbols in front are refined, from the text alone (csrc/lfirst.inc);
+    the result is the BWT the reference's TransformIterator gives (src/block/dc.rs:45-50).  Cases built for its parts: tile-crossing groups
+    (runs of equal 8-grams), groups that take the deep way (copies of long passages, also three and four of them), suffix 0 inside a
+    repeat (the origin needs its exact place), text ending in zero bytes (suffixes that end inside a key), blocks around the tile sizes."""
+    from dark_amd import datagen
+    rng = np.random.default_rng(77)
+    base = datagen.wiki_like(3_000_000, 12)
+    cases = []
+    t = base.copy()
+    seg = t[5000:45000].copy()
+    for o in (700_000, 1_900_000, 2_800_000):  # four copies of 40 KB
+        t[o:o + len(seg)] = seg
+    cases.append(("copies of copies", t, {"lfirst", "lfirst_deep"}))
+    t = base[:2_000_000].copy()
+    t[1_200_000:1_200_000 + 300_000] = t[:300_000]  # suffix 0 starts a 300 KB repeat
+    cases.append(("suffix 0 in a repeat", t, {"lfirst", "lfirst_deep"}))
+    t = np.concatenate([base[:1_500_000], np.zeros(9, np.uint8)])
+    cases.append(("ends in a few zeros", t, {"lfirst"}))
+    t = base[:1_000_000].copy()
+    t[300_000:300_000 + 5000] = 65  # a run of 5000 equal bytes: one group across tiles that never splits on text
+    cases.append(("a run inside text", t, set()))
+    for n in (65536, 65537, 2048 * 33, 2048 * 33 + 1, 1024 * 1024 + 3):
+        cases.append(("n = %d" % n, base[:n].copy(), {"lfirst"}))
+    with dark_amd.Context(max(len(t) for _, t, _ in cases)) as c:
+        for name, t, route in cases:
+            wb, wo = orc.bwt_forward(t)
+            bwt, origin = c.bwt_forward(t)
+            assert origin == wo and first_diff(bwt, wb) is None, name
+            assert route <= c.stats()["routes"], (name, c.stats()["routes"])
+            assert first_diff(c.bwt_inverse(bwt, origin), t) is None, name
+            stream = c.block_encode("dark", t)
+            assert stream == orc.block_dc_encode("dark", t), name
+    del rng
+
+
+def test_workspace_accounting(orc):
+    """a context sized exactly to its block must hold every stage's temporaries (csrc/abi.cpp workspace_bytes lists them) --
+    text, word-like text (marked SA entries, big groups), {A,C,G,T}, a period-2 block (pair-chain-free giant groups) and text with long
+    repeats (pair chains / deep groups), through the suffix array, the BWT, a block encode and a decode; the margin is printed."""
+    from dark_amd import datagen
+    n = 3_000_000
+    rng = np.random.default_rng(5)
+    cases = [datagen.wiki_like(n, 3), datagen.word_like(n, 8), datagen.acgt(n, 4), np.frombuffer(b"ab" * (n // 2), np.uint8),
+             np.concatenate([datagen.wiki_like(n // 2, 6)] * 2), rng.integers(0, 255, size=n, dtype=np.uint8)]
+    for t in cases:
+        t = np.ascontiguousarray(t)
+        with dark_amd.Context(len(t)) as c:
+            c.suffix_array(t)
+            bwt, origin = c.bwt_forward(t)
+            stream = c.block_encode("dark", t)
+            assert c.block_decode("dark", stream, len(t)) == t.tobytes()
+            st = c.stats()
+            assert 0 < st["ws_peak_bytes"] <= st["ws_size_bytes"]
+            print("n=%d peak %.1f n of %.1f n" % (len(t), st["ws_peak_bytes"] / len(t), st["ws_size_bytes"] / len(t)))

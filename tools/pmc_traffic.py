@@ -24,7 +24,8 @@ import sys
 GATHER_KERNELS = {"k_round_local", "k_plateau_sort", "k_plateau_ranks", "k_bwt_gather", "k_radix_scan",
                   "k_big_reduce", "k_big_spine", "k_big_apply", "k_big_back", "k_rerank_scan", "k_dc_carry_a", "k_dc_carry_b", "k_dc_carry_c",
                   "k_dc_runscan", "k_dc_sweep", "k_fill_u32", "k_place_active", "k_rank_active", "k_prefix_probe", "k_to_inplace",
-                  "k_plateau_scan", "k_chain_ends", "k_chain_verdicts", "k_chain_apply", "k_ibwt_walk", "k_ibwt_emit", "k_ibwt_jump", "k_isa_init"}
+                  "k_plateau_scan", "k_chain_ends", "k_chain_verdicts", "k_chain_apply", "k_ibwt_walk", "k_ibwt_emit", "k_ibwt_jump", "k_isa_init",
+                  "k_lf_finish", "k_lf_deep", "k_lf_straddle"}
 
 # dk_stats slot (dark_amd/csrc/context.hpp) of every kernel: a slot is named after its kernel, or after the common prefix of the kernels
 # one LaunchScope brackets; bench.py reports HIP-event times per slot, the rocprofv3 CSVs are per kernel
@@ -35,7 +36,8 @@ SLOT_OF = {"k_chain_extract": "k_chain", "k_chain_ends": "k_chain", "k_chain_til
            "k_big_reduce": "k_big_classify", "k_big_spine": "k_big_classify", "k_big_apply": "k_big_classify",
            "k_rank_active": "k_place_active", "k_to_inplace": "k_plateau_ranks", "k_plateau_count": "k_plateau_ranks",
            "k_plateau_scan": "k_plateau_ranks", "k_plateau_compact": "k_plateau_ranks",
-           "k_isa_init": "k_isa_partition", "k_isa_split": "k_isa_partition"}
+           "k_isa_init": "k_isa_partition", "k_isa_split": "k_isa_partition",
+           "k_lf_reduce": "k_rerank_reduce", "k_lf_straddle": "k_rerank_scan", "k_lf_apply": "k_rerank_apply", "k_lf_finish": "k_round_local", "k_lf_deep": "k_chain"}
 
 
 def short(name):
@@ -75,7 +77,7 @@ def main():
     ap.add_argument("write_dir")
     ap.add_argument("--steps", type=int, required=True, help="steps (warm-up + timed) the profiled command ran")
     ap.add_argument("--workload", required=True)
-    ap.add_argument("--round", type=int, default=3)
+    ap.add_argument("--round", type=int, default=4)
     args = ap.parse_args()
     fetch = collect(args.fetch_dir, "FETCH_SIZE")
     write = collect(args.write_dir, "WRITE_SIZE")
@@ -90,7 +92,8 @@ def main():
         total += hbm / args.steps
         kernels[k] = {"slot": SLOT_OF.get(k, k), "launches_per_step": launches / args.steps, "fetch_raw_bytes_per_step": round(fb / args.steps),
                       "fetch_correction": corr, "write_bytes_per_step": round(wb / args.steps),
-                      "hbm_bytes_per_launch": round(hbm / launches) if launches else 0}
+                      "hbm_bytes_per_launch": round(hbm / launches) if launches else 0,
+                      "raw_hbm_bytes_per_launch": round((fb + wb) / launches) if launches else 0}  # the counters as printed, no correction
     kernels = dict(sorted(kernels.items(), key=lambda kv: -(kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_per_step"])))
     # per slot, for bench.py: HBM bytes per step of all the kernels a slot brackets
     slots = {}
