@@ -66,6 +66,25 @@ __global__ __launch_bounds__(256) void k_sym_hist(const uint8_t *__restrict__ t,
     if (seen[threadIdx.x]) present[threadIdx.x] = 1;  // (plain store: every workgroup writes the same value)
 }
 
+// Is there a long run of one byte value?  A thread looks at one aligned 256-byte window; a run of at least 511 bytes holds a whole window.
+// (The L-first BWT path refines groups from the text: the suffixes inside a run of more than a few hundred equal bytes are one group that
+// never splits that way -- such blocks take the suffix-array path from the start instead of finding out after two rounds.)
+__global__ __launch_bounds__(256) void k_run_probe(const uint8_t *__restrict__ t, size_t n, uint32_t *__restrict__ flag) {
+    const size_t w = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t p = w * 256;
+    if (p + 256 > n || (reinterpret_cast<uintptr_t>(t) & 15) != 0) return;
+    const uint4 *q = reinterpret_cast<const uint4 *>(t + p);
+    const uint32_t first = q[0].x, rep = (first & 0xFFu) * 0x01010101u;
+    if (first != rep) return;
+    uint32_t diff = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint4 v = q[k];
+        diff |= (v.x ^ rep) | (v.y ^ rep) | (v.z ^ rep) | (v.w ^ rep);
+    }
+    if (diff == 0) *flag = 1u;
+}
+
 __global__ __launch_bounds__(256) void k_sa_descending(uint32_t *__restrict__ sa, size_t n) {
     const size_t j = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (j < n) sa[j] = static_cast<uint32_t>(n - 1 - j);
@@ -464,7 +483,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_rerank_apply(const uint8_t *__rest
         const uint32_t head_pos = hs >= b0 ? s_pos[hs - b0] : pos_in[hs];
         if (rank && !(el & 1u)) rank[suffix] = head_pos;  // members of a group that kept its head keep their rank: no scatter
         if (!(f & F_SURV)) {  // the group is a singleton: this suffix is in its final place
-            sa[my_pos[j]] = suffix;
+            if (sa) sa[my_pos[j]] = suffix;  // (null: a BWT caller behind the rank array's construction -- nobody reads SA again, L is what counts)
             if (bc.bwt) {
                 bc.bwt[my_pos[j]] = static_cast<uint8_t>(sym8 >> (8 * j));
                 if (suffix == 0) *bc.origin = my_pos[j];
@@ -1043,7 +1062,7 @@ __global__ __launch_bounds__(LS_BLOCK) void k_plateau_sort(const uint32_t *__res
         meta_out[dest[k]] = meta_new[k];
         if (fin_pos[k] != ~0u) {  // final
             const uint32_t p = fin_pos[k];
-            sa[p] = my_idx[k];
+            if (sa) sa[p] = my_idx[k];
             if (sym_in) bwt[p] = my_sym[k];
             if (origin && my_idx[k] == 0) *origin = p;
             idx_out[dest[k]] = my_idx[k] | PL_DEAD_BIT;  // k_plateau_ranks still needs the suffix; dead for every later round
@@ -1211,8 +1230,10 @@ __global__ __launch_bounds__(256) void k_chain_apply(uint32_t *__restrict__ idx,
     const bool x_first = (x < y) == (v == CH_LT);  // x is the smaller SUFFIX
     const uint32_t p0 = pos[a], p1 = pos[a + 1];
     const uint32_t first = x_first ? x : y, second = x_first ? y : x;
-    sa[p0] = first;
-    sa[p1] = second;
+    if (sa) {
+        sa[p0] = first;
+        sa[p1] = second;
+    }
     if (bwt) {
         const uint8_t sx = sym[a], sy = sym[a + 1];
         bwt[p0] = x_first ? sx : sy;
@@ -1334,14 +1355,16 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
 
     // 1. alphabet
     uint32_t *d_hist = ctx->d_mail + 16;
-    DK_HIP(ctx, hipMemsetAsync(d_hist, 0, 256 * sizeof(uint32_t), st));
+    DK_HIP(ctx, hipMemsetAsync(d_hist, 0, 257 * sizeof(uint32_t), st));  // (+ the run probe's word behind the 256 counters)
     {
         LaunchScope ls(ctx, K_SYM_HIST, 1.0 * n);
         const size_t blocks = std::min<size_t>(div_up(n, 256 * 64), 2048);
         k_sym_hist<<<dim3(blocks), dim3(256), 0, st>>>(d_text, n, d_hist);
+        if (d_bwt && allow_lfirst && n >= (1u << 16)) k_run_probe<<<dim3(div_up(div_up(n, 256), 256)), dim3(256), 0, st>>>(d_text, n, d_hist + 256);
     }
-    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 16, d_hist, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 16, d_hist, 257 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     DK_HIP(ctx, hipStreamSynchronize(st));
+    const bool long_run = ctx->h_mail[16 + 256] != 0;
     uint8_t code[256];
     unsigned sigma = 0;
     for (int s = 0; s < 256; ++s) {
@@ -1462,7 +1485,7 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
     // Not where the probe saw a quarter of its sample in big groups (lfirst_path would find the same after a rerank, see there), and not
     // behind a shortened key: next to nothing survives such a sort, and the uniformity test costs the first rerank more than it saves
     // (2^30 random bytes: reduce 2.3 against 1.1 ms, nothing else differs; 2^28 {A,C,G,T}: 8.63 against 8.56 ms).
-    if (carry_bwt && allow_lfirst && lf_mode != 0 && (lf_mode == 2 || (n >= (1u << 16) && probe_big_share <= 0.25 && !short_prefix))) {
+    if (carry_bwt && allow_lfirst && lf_mode != 0 && (lf_mode == 2 || (n >= (1u << 16) && probe_big_share <= 0.25 && !short_prefix && !long_run))) {
         const LfBuffers b{keys_alt, keys_3, vals_3, vals, rank, sym_alt, vals_alt, pos, gid, sym, gstart, bigidx, bigoff};
         bool done = false, pristine = true;
         route |= DK_ROUTE_LFIRST;
@@ -1543,7 +1566,10 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
         // keys / vals_alt (/ sym_alt) now hold every group sorted by its secondary key in its own slot range
         size_t next_active = 0, next_groups = 0, next_big = 0, next_medium = 0, next_biggroups = 0;
         const BwtCarry bc{0, carry_bwt ? d_bwt : nullptr, nullptr, d_origin, sym_alt, sym};
-        DK_TRY(rerank(ctx, keys, vals_alt, pos, active, gid, have_ranks ? rank : nullptr, d_sa, vals, pos_alt, gid_alt, gstart, bc));
+        // SA entries of suffixes that become final after the rank array exists are read by nobody when the caller wants L (the inverse
+        // permutation was the last reader): 84 M scattered 4-byte stores less on 1e8 bytes of word-like text
+        uint32_t *sa_out = carry_bwt && have_ranks ? nullptr : d_sa;
+        DK_TRY(rerank(ctx, keys, vals_alt, pos, active, gid, have_ranks ? rank : nullptr, sa_out, vals, pos_alt, gid_alt, gstart, bc));
         DK_TRY(classify_and_read(ctx, active / 2, gstart, bigidx, bigoff, &next_active, &next_groups, &next_big, &next_medium, &next_biggroups));
         std::swap(pos, pos_alt);
         std::swap(gid, gid_alt);
@@ -1646,7 +1672,7 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
                     k_chain_tiles<<<dim3(ntiles), dim3(256), 0, st>>>(rec_verdict, m, tile_max);
                     k_chain_spine<<<dim3(1), dim3(1024), 0, st>>>(tile_max, ntiles);
                     k_chain_verdicts<<<dim3(ntiles), dim3(256), 0, st>>>(rec_verdict, rec_slot, m, tile_max, slot_verdict);
-                    k_chain_apply<<<dim3(div_up(slots, 256)), dim3(256), 0, st>>>(idx_a, sym_a, pos, slot_verdict, slots, d_sa, carry_bwt ? d_bwt : nullptr, d_origin, rank);
+                    k_chain_apply<<<dim3(div_up(slots, 256)), dim3(256), 0, st>>>(idx_a, sym_a, pos, slot_verdict, slots, carry_bwt ? nullptr : d_sa, carry_bwt ? d_bwt : nullptr, d_origin, rank);
                 }
                 DK_HIP(ctx, hipGetLastError());
                 ctx->ws_release(mark2);
@@ -1661,7 +1687,7 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
             {
                 LaunchScope ls(ctx, K_PLATEAU_SORT, 6.0 * slots + 4.0 * live + 10.0 * live);
                 k_plateau_sort<<<dim3(div_up(slots, LS_TILE)), dim3(LS_BLOCK), 0, st>>>(idx_a, meta_a, sym_a, pos, rank, static_cast<uint32_t>(n), h_eff,
-                                                                                      slots, idx_b, meta_b, sym_b, d_sa, d_bwt, d_origin, cnt,
+                                                                                      slots, idx_b, meta_b, sym_b, carry_bwt ? nullptr : d_sa, d_bwt, d_origin, cnt,
                                                                                       launched ? d_live + ((launched - 1) & 7u) : nullptr);
             }
             {

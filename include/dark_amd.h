@@ -214,6 +214,7 @@ typedef struct dk_stats {
 #define DK_ROUTE_LFIRST 0x400u          /* BWT callers: only groups with different symbols in front were refined (no suffix array) */
 #define DK_ROUTE_LFIRST_BIG_ROUND 0x800u  /* ... with at least one global-sort round of big groups */
 #define DK_ROUTE_LFIRST_DEEP 0x1000u    /* ... and groups that went the way of long repeats (common extension measured directly) */
+#define DK_ROUTE_LFIRST_GIANT 0x4000u    /* ... and common extensions longer than 64 KiB, measured by the whole grid (copies of whole files) */
 #define DK_ROUTE_LFIRST_FALLBACK 0x2000u  /* the L-first path gave up (giant groups / over-long common extensions): suffix-array path from the start */
 /* enable (1) / disable (0) HIP-event bracketing of every kernel launch on the context's stream */
 int dk_set_profiling(dk_ctx *ctx, int enabled);

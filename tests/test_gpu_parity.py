@@ -525,8 +525,15 @@ def test_lfirst_bwt_without_the_suffix_array(orc):
     t = np.concatenate([base[:1_500_000], np.zeros(9, np.uint8)])
     cases.append(("ends in a few zeros", t, {"lfirst"}))
     t = base[:1_000_000].copy()
-    t[300_000:300_000 + 5000] = 65  # a run of 5000 equal bytes: one group across tiles that never splits on text
-    cases.append(("a run inside text", t, set()))
+    t[300_000:300_000 + 5000] = 65  # a run of 5000 equal bytes: one group that never splits on text -- seen by the run probe, suffix-array path
+    cases.append(("a run inside text", t, {"general_round"}))
+    t = base[:1_000_000].copy()
+    t[300_000:300_000 + 400] = 65   # a run the probe does not see (no whole 256-byte window... or one): correct either way
+    cases.append(("a short run inside text", t, set()))
+    cases.append(("two identical halves", np.concatenate([base[:1_200_000]] * 2), {"lfirst", "lfirst_giant"}))   # one pair with 1.2 MB in common
+    cases.append(("three copies", np.concatenate([base[:800_000]] * 3), {"lfirst", "lfirst_giant"}))            # ... and a triple: two giant rounds
+    t = np.concatenate([base[:700_000], base[100_000:700_000], base[:700_000]])                                   # copies inside copies
+    cases.append(("copies inside copies", t, {"lfirst", "lfirst_giant"}))
     for n in (65536, 65537, 2048 * 33, 2048 * 33 + 1, 1024 * 1024 + 3):
         cases.append(("n = %d" % n, base[:n].copy(), {"lfirst"}))
     with dark_amd.Context(max(len(t) for _, t, _ in cases)) as c:

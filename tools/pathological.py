@@ -43,6 +43,7 @@ def cases(mode):
             "ab*5e7 (1e8 bytes, period 2)": lambda: np.frombuffer(b"ab" * 50_000_000, np.uint8),
             "two identical 50 MB halves (1e8 bytes)": lambda: np.concatenate([half, half]),
             "a^n b 1e8": lambda: np.concatenate([np.zeros(100_000_000 - 1, np.uint8), np.ones(1, np.uint8)]),
+            "text with a 3000-byte run of zeros (1e8 bytes)": lambda: np.concatenate([half, np.zeros(3000, np.uint8), half[:50_000_000 - 3000][::-1]]),
         })
     return out
 
@@ -72,6 +73,7 @@ def main():
             want_bwt, want_origin = orc.bwt_forward(t, want)
             ok = bool((d_sa.cpu().numpy().view(np.uint32) == want).all()) and origin == want_origin and bool((d_bwt.cpu().numpy() == want_bwt).all())
             res = {"case": name, "bytes": n, "gpu_ms": round(1e3 * best, 2), "gpu_MBps": round(n / best / 1e6, 1), "rounds": st["rounds"],
+                   "bwt_routes": sorted(st["routes"]),
                    "sort_passes": st["sort_passes"], "oracle_sais_s": round(dto, 2), "oracle_MBps": round(n / dto / 1e6, 1), "equal_to_oracle": ok}
             print(json.dumps(res), flush=True)
             results.append(res)
