@@ -1406,8 +1406,8 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
             const int k = (8 * passes) / bits;
             if (k >= 1 && k < spk && (cands.count == 0 || cands.sym[cands.count - 1] != k)) cands.sym[cands.count++] = k;
         }
-        if (cands.count > 0 && (prefix_mode == 2 || prefix_mode == 3)) {
-            spk_sort = cands.sym[prefix_mode == 3 && cands.count > 1 ? 1 : 0];
+        if (cands.count > 0 && prefix_mode >= 2 && prefix_mode <= 4) {  // (4: the third candidate, six passes -- an experiment hook)
+            spk_sort = cands.sym[std::min(prefix_mode - 2, cands.count - 1)];
         } else if (cands.count > 0) {
             const uint32_t m = static_cast<uint32_t>(std::min<double>(n / 2.0, 10.0 * std::sqrt(static_cast<double>(n))));
             const uint32_t span = static_cast<uint32_t>(n / m);
