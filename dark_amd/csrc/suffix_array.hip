@@ -1585,6 +1585,43 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
         return DK_OK;
     };
 
+    // A caller that wants L: once the big groups hold little of what is active (doubling has broken them up, or there never were many behind
+    // a shortened key), the rest is finished the L-first way (lfirst.inc: only the groups with different symbols in front, from the text,
+    // inside LDS) instead of more rounds on ranks, pair chains and in-place rounds.  DK_LF_SWITCH: per cent of the active slots that may
+    // still sit in big groups at the switch (0: never).  -> 1: L is complete; 0: not taken; -1: it gave up half way (start over).
+    // Measured, round 4 (1e8 bytes of word-like text, suffix-array path 20.7 ms): switch at 1 % 20.4, at 5 % 19.3-20.1, at 25 % 21.2, at 40-60 %
+    // 22.9, at 80 % (= L-first from the start) 20.5 ms -- and 5 % costs inputs whose big groups do not split on text (90 % zeros: 1.8 -> 2.9 ms
+    // at 5 MB) more than it gains here.  Off in the product; the tuning build keeps the switch and tests/test_env_variants.py the parity.
+    const int lf_switch = DK_KNOB("DK_LF_SWITCH", 0);
+    auto take_over = [&](int *outcome) -> int {
+        *outcome = 0;
+        if (!(carry_bwt && allow_lfirst && lf_mode != 0 && lf_switch > 0 && !long_run && n >= (1u << 16) && active > 0 &&
+              nbig * 100 <= active * static_cast<size_t>(lf_switch)))
+            return DK_OK;
+        if (nbig > 0 && nbig / nbiggroups > LF_AVG_BIG) return DK_OK;  // giant groups (periodic input) are doubling's business
+        // buffers: everything but the current list is free between rounds; the key buffer that is not a sort's ping-pong partner holds the
+        // big list's second suffix array and its symbols (4 n + n of its 8 n bytes); the rank array becomes the big list's positions
+        uint32_t *spare = reinterpret_cast<uint32_t *>(keys);
+        const LfBuffers b{keys_alt, keys_3, vals_3, spare, rank, reinterpret_cast<uint8_t *>(spare + n), vals_alt, pos_alt, gid_alt, sym_alt, gstart, bigidx, bigoff};
+        const LfFrom from{vals, pos, gid, sym, active};
+        bool done = false, pristine = true;
+        if (trace) fprintf(stderr, "[dk] %zu active, %zu of them in big groups, depth %llu: the L-first path takes over\n", active, nbig, (unsigned long long)h);
+        route |= DK_ROUTE_LFIRST;
+        DK_TRY(lfirst_path(ctx, d_text, n, nullptr, 0, nullptr, nullptr, d_bwt, d_origin, b, static_cast<uint32_t>(std::min<uint64_t>(h, n)), trace, true, &done, &pristine, &from));
+        *outcome = done ? 1 : -1;
+        return DK_OK;
+    };
+#define DK_TAKE_OVER()                                                                                                      \
+    do {                                                                                                                    \
+        int outcome_ = 0;                                                                                                   \
+        DK_TRY(take_over(&outcome_));                                                                                       \
+        if (outcome_ > 0) { ctx->ws_release(mark); *bwt_written = true; return DK_OK; }                                     \
+        if (outcome_ < 0) {                                                                                                 \
+            ctx->ws_release(mark);                                                                                          \
+            return suffix_array_impl(ctx, d_text, n, d_sa, d_bwt, d_origin, bwt_written, false);                            \
+        }                                                                                                                   \
+    } while (0)
+
     // 5a. extend the survivors' keys from the text: up to floor(63 / bits) further symbols per round, no ranks needed.  A second
     //     such round only when the first left a lot (otherwise what is left are long repeats, which want doubling).
     for (int t = 0; !have_ranks && active > 0 && t < 2; ++t) {
@@ -1598,6 +1635,7 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
         DK_TRY(run_round(std::min<int>(std::min(spk, 63 / bits), static_cast<int>(std::min<uint64_t>(h, 64))), &adv));
         h += static_cast<uint64_t>(adv);
     }
+    DK_TAKE_OVER();
     // 5b. survivors beyond that (long repeats): build the rank array the doubling rounds need
     if (active > 0 && !have_ranks) {
         // up to 2^27 suffixes the inverse permutation goes through LDS windows and can hand every active suffix the position of its
@@ -1627,6 +1665,7 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
         if (ctx->stats.rounds > 44) return ctx->fail(DK_E_INTERNAL, "suffix_array: no convergence after 44 rounds");
         DK_TRY(run_round(0, nullptr));
         h *= 2;
+        DK_TAKE_OVER();
     }
     // ... then in place (k_plateau_sort): one sort kernel + one rank kernel per round, the live count read back one round late
     if (active > 0) {
@@ -1752,6 +1791,7 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
     if (carry_bwt) *bwt_written = true;
     ctx->ws_release(mark);
     return DK_OK;
+#undef DK_TAKE_OVER
 }
 
 }  // namespace

@@ -148,7 +148,8 @@ def test_entropy_error_paths_return_codes(threads):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"DK_XCD": "0"}, {"DK_DIGIT_PLANE": "1"}, {"DK_PLATEAU": "0"}, {"DK_BWT_CARRY": "0"},
                                  {"DK_PLATEAU": "0", "DK_BWT_CARRY": "0"}, {"DK_PAIR_CHAINS": "0"}, {"DK_PAIR_CHAINS": "1", "DK_BWT_CARRY": "0"},
-                                 {"DK_LFIRST": "0"}, {"DK_LFIRST": "2"}, {"DK_LFIRST": "2", "DK_LF_MAX": "32"}])
+                                 {"DK_LFIRST": "0"}, {"DK_LFIRST": "2"}, {"DK_LFIRST": "2", "DK_LF_MAX": "32"}, {"DK_LF_SWITCH": "40"},
+                                 {"DK_LF_SWITCH": "100"}])
 def test_gpu_variants_match_oracle(env):
     _run(GPU_SNIPPET, env, tuning=True)
 

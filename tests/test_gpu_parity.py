@@ -528,8 +528,11 @@ def test_lfirst_bwt_without_the_suffix_array(orc):
     t[300_000:300_000 + 5000] = 65  # a run of 5000 equal bytes: one group that never splits on text -- seen by the run probe, suffix-array path
     cases.append(("a run inside text", t, {"general_round"}))
     t = base[:1_000_000].copy()
-    t[300_000:300_000 + 400] = 65   # a run the probe does not see (no whole 256-byte window... or one): correct either way
-    cases.append(("a short run inside text", t, set()))
+    t[300_033:300_033 + 300] = 65   # a run the probe does not see (it starts one byte behind a 256-byte border): a group of ~290 members that does not
+    cases.append(("a short run inside text", t, {"lfirst", "lfirst_big_round", "lfirst_deep"}))  # split on text -- k_lf_deep orders it by common extensions
+    t = base[:1_000_000].copy()
+    t[500_001:500_001 + 3 * 160] = np.frombuffer(b"xyz" * 160, np.uint8)  # a periodic stretch: the same, period 3
+    cases.append(("a periodic stretch inside text", t, {"lfirst"}))
     cases.append(("two identical halves", np.concatenate([base[:1_200_000]] * 2), {"lfirst", "lfirst_giant"}))   # one pair with 1.2 MB in common
     cases.append(("three copies", np.concatenate([base[:800_000]] * 3), {"lfirst", "lfirst_giant"}))            # ... and a triple: two giant rounds
     t = np.concatenate([base[:700_000], base[100_000:700_000], base[:700_000]])                                   # copies inside copies

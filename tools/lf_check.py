@@ -30,6 +30,9 @@ cases = [
     ("ends in zeros", np.concatenate([rng.integers(0, 256, size=n - 3000, dtype=np.uint8), np.zeros(3000, np.uint8)])),
     ("zeros then text then zeros", np.concatenate([np.zeros(5000, np.uint8), datagen.wiki_like(n - 10000, 3), np.zeros(5000, np.uint8)])),
     ("period 1000", np.tile(rng.integers(0, 256, size=1000, dtype=np.uint8), n // 1000 + 1)[:n].copy()),
+    ("text with a 400-byte run", np.concatenate([datagen.wiki_like(n // 2, 13), np.full(400, 65, np.uint8), datagen.wiki_like(n // 2, 14)])),
+    ("text with 300 x abc", np.concatenate([datagen.wiki_like(n // 2, 15), np.frombuffer(b"abc" * 300, np.uint8), datagen.wiki_like(n // 2, 16)])),
+    ("text with runs of 100..500", (lambda t: [t.__setitem__(slice(o, o + int(l)), 32) for o, l in zip(rng.integers(0, n - 600, 200), rng.integers(100, 500, 200))] and t)(datagen.wiki_like(n, 17).copy())),
     ("small text 70000", datagen.wiki_like(70_000, 4)),
     ("tiny", rng.integers(0, 3, size=70, dtype=np.uint8)),
 ]
