@@ -68,7 +68,14 @@ with dark_amd.Context(6 << 20) as ctx:
     vals = np.arange(len(keys), dtype=np.uint32)
     k2, v2 = ctx.dbg_sort_pairs(keys, vals, 0, 64)
     assert (v2 == vals[np.argsort(keys, kind="stable")]).all()
-    for t in (datagen.wiki_like(4500000, 7), np.frombuffer(b"ab" * 50000, np.uint8), rng.integers(0, 4, size=300000, dtype=np.uint8)):
+    def copies(odd):  # 5000 copies of a passage behind one byte value, one copy behind another: groups across many tiles, one of them live
+        seg = rng.integers(97, 123, size=40, dtype=np.uint8)
+        parts = []
+        for k in range(5000):
+            parts += [rng.integers(0, 255, size=int(rng.integers(20, 60)), dtype=np.uint8), np.array([66 if k == odd else 65], np.uint8), seg]
+        return np.concatenate(parts + [rng.integers(0, 255, size=50000, dtype=np.uint8)])
+    for t in (datagen.wiki_like(4500000, 7), np.frombuffer(b"ab" * 50000, np.uint8), rng.integers(0, 4, size=300000, dtype=np.uint8), copies(0), copies(2500),
+              copies(4999)):
         t = np.ascontiguousarray(t)
         want = orc.sa_sais(t)
         assert (ctx.suffix_array(t) == want).all()

@@ -539,6 +539,19 @@ def test_lfirst_bwt_without_the_suffix_array(orc):
     cases.append(("copies inside copies", t, {"lfirst", "lfirst_giant"}))
     for n in (65536, 65537, 2048 * 33, 2048 * 33 + 1, 1024 * 1024 + 3):
         cases.append(("n = %d" % n, base[:n].copy(), {"lfirst"}))
+    # groups that cross many 2048-slot tiles (k_lf_straddle): 9000 copies of a 40-byte passage, each behind the same byte -- except one copy,
+    # the first / a middle / the last in the text (= in its group after the stable initial sort): the one group that starts with the
+    # passage's first byte is live because of a single member far from the tiles most of it lies in; the 39 others are not
+    seg = rng.integers(97, 123, size=40, dtype=np.uint8)
+    for odd in (0, 4500, 8999):
+        parts = []
+        for k in range(9000):
+            parts += [rng.integers(0, 256, size=int(rng.integers(20, 60)), dtype=np.uint8), np.array([66 if k == odd else 65], np.uint8), seg]
+        t = np.concatenate(parts + [rng.integers(0, 256, size=100_000, dtype=np.uint8)])
+        t[t == 255] = 0
+        # (the live group is big and holds nearly everything that is live: the first rerank decides all forty groups across their tiles, then
+        # the suffix-array path goes on; tests/test_env_variants.py runs the same shape with the L-first path forced)
+        cases.append(("tile-crossing groups, odd copy %d" % odd, t, {"lfirst_fallback"}))
     with dark_amd.Context(max(len(t) for _, t, _ in cases)) as c:
         for name, t, route in cases:
             wb, wo = orc.bwt_forward(t)
