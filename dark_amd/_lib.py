@@ -77,6 +77,8 @@ SIGNATURES = {
     "dk_last_entropy_info": (None, [C.POINTER(_i), C.POINTER(_i)]),
     "dk_dbg_stream_encode_gated": (_i, [_i, _sz, _vp, _vp, _vp, _sz, C.c_uint32, _vp, _sz, _szp, _vp, C.c_uint, _i]),
     "dk_dbg_sort_pairs": (_i, [_vp, _vp, _vp, _sz, _i, _i]),
+    "dk_dbg_dev_sort_pairs": (_i, [_vp, _vp, _vp, _sz, _i, _i]),
+    "dk_dbg_dev_local_sort": (_i, [_vp, _vp, _vp, _sz, _i, _i]),
 }
 
 _lib = None

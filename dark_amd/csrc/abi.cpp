@@ -939,6 +939,27 @@ int dk_dbg_stream_encode_gated(int model_id, size_t n, const uint32_t init[256],
     s.stall_ms = stall_ms;
     return encode_block_stream(model_id, s, out, out_cap, out_len, host_threads);
 }
+int dk_dbg_dev_local_sort(dk_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, size_t count, int begin_bit, int end_bit) {
+    DK_TRY(begin_call(ctx));
+    ScopedCall sc(ctx);
+    if (!d_keys || !d_vals) return ctx->fail(DK_E_ARG, "null pointer");
+    return local_sort_tiles(ctx, d_keys, d_vals, count, begin_bit, end_bit);
+}
+int dk_dbg_dev_sort_pairs(dk_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, size_t count, int begin_bit, int end_bit) {
+    DK_TRY(begin_call(ctx));
+    ScopedCall sc(ctx);
+    if (!d_keys || !d_vals || count == 0) return ctx->fail(DK_E_ARG, "null pointer or empty input");
+    uint64_t *k0 = d_keys, *k1 = ctx->ws_alloc<uint64_t>(count);
+    uint32_t *v0 = d_vals, *v1 = ctx->ws_alloc<uint32_t>(count);
+    if (!k1 || !v1) return DK_E_NOMEM;
+    DK_TRY(sort_pairs(ctx, k0, k1, v0, v1, count, begin_bit, end_bit));
+    if (k0 != d_keys) {
+        DK_HIP(ctx, hipMemcpyAsync(d_keys, k0, count * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        DK_HIP(ctx, hipMemcpyAsync(d_vals, v0, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DK_OK;
+}
 int dk_dbg_sort_pairs(dk_ctx *ctx, uint64_t *keys, uint32_t *vals, size_t count, int begin_bit, int end_bit) {
     DK_TRY(begin_call(ctx));
     ScopedCall sc(ctx);

@@ -477,8 +477,16 @@ constexpr int SS_WAVES = SS_BLOCK / 64;
 constexpr int SS_KPT = 8;
 constexpr int SS_MAX = SS_BLOCK * SS_KPT;  // 8192 pairs
 
+// (a grid of more than one workgroup: workgroup b sorts the pairs [b * SS_MAX, (b + 1) * SS_MAX) by themselves -- the local pass of an
+// MSD-first sort, measured in round 4: dk_dbg_dev_local_sort)
 __global__ __launch_bounds__(SS_BLOCK) void k_radix_sort_small(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t count,
                                                                int begin_bit, int end_bit) {
+    {
+        const size_t base = static_cast<size_t>(blockIdx.x) * SS_MAX;
+        keys += base;
+        vals += base;
+        count = count - base < static_cast<size_t>(SS_MAX) ? static_cast<uint32_t>(count - base) : static_cast<uint32_t>(SS_MAX);
+    }
     __shared__ uint64_t s_keys[SS_MAX];
     __shared__ uint32_t s_vals[SS_MAX];
     __shared__ uint32_t s_cnt[SS_WAVES][256];
@@ -656,6 +664,18 @@ int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&val
         return DK_OK;
     }
     return sort_pairs_classic(ctx, keys, keys_alt, vals, vals_alt, count, begin_bit, end_bit, text, final_out);
+}
+
+// experiment hook (tools/local_sort_bench.py): every SS_MAX-pair tile of a device array sorted by itself on bits [begin_bit, end_bit)
+int local_sort_tiles(dk_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, size_t count, int begin_bit, int end_bit) {
+    if (count == 0 || count > 0xFFFFFFFFull) return ctx->fail(DK_E_ARG, "local_sort_tiles: count");
+    {
+        LaunchScope ls(ctx, K_RADIX_SORT_SMALL, 24.0 * count);
+        k_radix_sort_small<<<dim3(static_cast<unsigned>(div_up(count, SS_MAX))), dim3(SS_BLOCK), 0, ctx->stream>>>(d_keys, d_vals, static_cast<uint32_t>(count), begin_bit, end_bit);
+    }
+    DK_HIP(ctx, hipGetLastError());
+    DK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DK_OK;
 }
 
 // ---- bucketed scatter: dst[idx[i]] = val[i] for a huge, random idx ---------------------------------------------------

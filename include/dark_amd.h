@@ -244,6 +244,11 @@ int dk_dbg_stream_encode_gated(int model_id, size_t n, const uint32_t init[256],
                                int host_threads);
 /* stable LSD radix sort of (u64 key, u32 value) pairs on bits [begin_bit, end_bit) -- the workhorse of the suffix sort */
 int dk_dbg_sort_pairs(dk_ctx *ctx, uint64_t *keys, uint32_t *vals, size_t count, int begin_bit, int end_bit);
+/* the same on device arrays, in place (measurement: tools/local_sort_bench.py) */
+int dk_dbg_dev_sort_pairs(dk_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, size_t count, int begin_bit, int end_bit);
+/* every 8192-pair tile of a device array sorted by itself inside one workgroup's LDS (the local pass an MSD-first sort would end with:
+ * an experiment of round 4) */
+int dk_dbg_dev_local_sort(dk_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, size_t count, int begin_bit, int end_bit);
 
 #ifdef __cplusplus
 }
