@@ -1163,6 +1163,8 @@ __attribute__((noinline)) int code_uniform(URing &ring, uint8_t *out, size_t cap
                 uint32_t lo = low + r * ev[k].from, h = low + r * ev[k].to, s = r * (ev[k].to - ev[k].from);
                 const uint32_t x = lo ^ h;
                 if (__builtin_expect(r == 0 || x == 0, 0)) { err = DK_E_INTERNAL; break; }
+                // (branch-free on purpose.  Five events in six leave no byte, and a branch would take the shift off the span's dependent
+                // chain when predicted: measured in round 4, 423.7 against 393.9 ms per 1e8-byte block -- the predictor does not see it coming.)
                 const unsigned sh = static_cast<unsigned>(__builtin_clz(x)) & 24u;
                 const uint32_t be = __builtin_bswap32(lo);
                 std::memcpy(p, &be, 4);
