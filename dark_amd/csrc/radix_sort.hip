@@ -714,7 +714,8 @@ __global__ __launch_bounds__(RS_BLOCK) void k_bucket_store(const uint64_t *__res
 // Algorithmic bytes: (4 n + 8 n) + (8 n + 8 n) + (8 n + 4 n) = 40 n.
 constexpr int ISA_BLOCK = 1024;
 constexpr int ISA_WBITS = 15;                 // largest window = 32768 words = 128 KiB of LDS
-constexpr size_t ISA_MAX_N = size_t(1) << (ISA_WBITS + 12);  // at most 64 sections x 64 windows
+constexpr size_t ISA_TWO_LEVELS_N = size_t(1) << (ISA_WBITS + 12);  // at most 64 sections x 64 windows
+constexpr size_t ISA_MAX_N = size_t(1) << 32;                       // three levels (round 4): 64 x 64 x 64 windows of 2^15 words -- every block there is
 constexpr int ISP_BLOCK = 256, ISP_IPT = 16, ISP_TILE = ISP_BLOCK * ISP_IPT;  // 4096 pairs per workgroup (8192 with 512 threads: the same 0.95 ms)
 
 // counters[d] = first index of bin d (bins of 2^shift entries)
@@ -814,28 +815,41 @@ __global__ __launch_bounds__(ISA_BLOCK) void k_isa_assemble(const uint64_t *__re
 // rank[sa[p]] = p; sa must be a permutation of 0..n-1, n <= ISA_MAX_N; scratch_a / scratch_b hold n u64 each
 static int inverse_permutation_windows(dk_ctx *ctx, const uint32_t *sa, size_t n, uint64_t *scratch_a, uint64_t *scratch_b, uint32_t *rank,
                                        const uint32_t *marked_val) {
-    const int wbits = n > (size_t(1) << (10 + 12)) ? static_cast<int>(ceil_log2_u64(n)) - 12 : 10;  // at most 4096 windows of at least 1024 words
+    // up to 2^27 entries: at most 4096 windows of at least 1024 words (two levels: sections, windows); above (round 4, blocks of 135 MB .. 2 GiB
+    // on the suffix-array path: it was the bucketed store with its 5.7 x write amplification): windows of 2^15 words and a third level in
+    // front -- at most 64 super-sections of 64 sections of 64 windows
+    const bool three_levels = n > ISA_TWO_LEVELS_N;
+    const int wbits = three_levels ? ISA_WBITS : n > (size_t(1) << (10 + 12)) ? static_cast<int>(ceil_log2_u64(n)) - 12 : 10;
     const uint32_t nwin = static_cast<uint32_t>(div_up(n, size_t(1) << wbits));
     const bool two_levels = nwin > 64;
     const uint32_t nsec = two_levels ? static_cast<uint32_t>(div_up(nwin, 64)) : 0;
+    const uint32_t nsup = three_levels ? static_cast<uint32_t>(div_up(nsec, 64)) : 0;
     const size_t ntiles = div_up(n, ISP_TILE);
     const size_t mark = ctx->ws_mark();
-    uint32_t *counters = ctx->ws_alloc<uint32_t>(64 + static_cast<size_t>(nsec ? nsec : 1) * 64);
+    uint32_t *counters = ctx->ws_alloc<uint32_t>(64 + static_cast<size_t>(nsup ? nsup : 1) * 64 + static_cast<size_t>(nsec ? nsec : 1) * 64);
     if (!counters) return DK_E_NOMEM;
-    uint32_t *sec_counters = counters, *win_counters = counters + 64;
+    uint32_t *top_counters = counters, *mid_counters = counters + 64, *win_counters = mid_counters + static_cast<size_t>(nsup ? nsup : 1) * 64;
     hipStream_t st = ctx->stream;
     uint64_t *by_window = scratch_a;
     {
-        LaunchScope ls(ctx, K_ISA_PARTITION, (two_levels ? 28.0 : 12.0) * n);
-        if (two_levels) {
-            k_isa_init<<<dim3(1), dim3(256), 0, st>>>(sec_counters, nsec, wbits + 6);
+        LaunchScope ls(ctx, K_ISA_PARTITION, (three_levels ? 44.0 : two_levels ? 28.0 : 12.0) * n);
+        if (three_levels) {
+            k_isa_init<<<dim3(1), dim3(256), 0, st>>>(top_counters, nsup, wbits + 12);
+            k_isa_init<<<dim3(div_up(nsup * 64, 256)), dim3(256), 0, st>>>(mid_counters, nsup * 64, wbits + 6);
             k_isa_init<<<dim3(div_up(nsec * 64, 256)), dim3(256), 0, st>>>(win_counters, nsec * 64, wbits);
-            k_isa_split<true><<<dim3(ntiles), dim3(ISP_BLOCK), 0, st>>>(sa, nullptr, n, wbits + 6, 0, sec_counters, scratch_a, marked_val);
+            k_isa_split<true><<<dim3(ntiles), dim3(ISP_BLOCK), 0, st>>>(sa, nullptr, n, wbits + 12, 0, top_counters, scratch_a, marked_val);
+            k_isa_split<false><<<dim3(ntiles), dim3(ISP_BLOCK), 0, st>>>(nullptr, scratch_a, n, wbits + 6, wbits + 12, mid_counters, scratch_b, nullptr);
+            k_isa_split<false><<<dim3(ntiles), dim3(ISP_BLOCK), 0, st>>>(nullptr, scratch_b, n, wbits, wbits + 6, win_counters, scratch_a, nullptr);
+            by_window = scratch_a;
+        } else if (two_levels) {
+            k_isa_init<<<dim3(1), dim3(256), 0, st>>>(top_counters, nsec, wbits + 6);
+            k_isa_init<<<dim3(div_up(nsec * 64, 256)), dim3(256), 0, st>>>(win_counters, nsec * 64, wbits);
+            k_isa_split<true><<<dim3(ntiles), dim3(ISP_BLOCK), 0, st>>>(sa, nullptr, n, wbits + 6, 0, top_counters, scratch_a, marked_val);
             k_isa_split<false><<<dim3(ntiles), dim3(ISP_BLOCK), 0, st>>>(nullptr, scratch_a, n, wbits, wbits + 6, win_counters, scratch_b, nullptr);
             by_window = scratch_b;
         } else {
-            k_isa_init<<<dim3(1), dim3(256), 0, st>>>(sec_counters, nwin, wbits);
-            k_isa_split<true><<<dim3(ntiles), dim3(ISP_BLOCK), 0, st>>>(sa, nullptr, n, wbits, 0, sec_counters, scratch_a, marked_val);
+            k_isa_init<<<dim3(1), dim3(256), 0, st>>>(top_counters, nwin, wbits);
+            k_isa_split<true><<<dim3(ntiles), dim3(ISP_BLOCK), 0, st>>>(sa, nullptr, n, wbits, 0, top_counters, scratch_a, marked_val);
         }
     }
     {

@@ -199,3 +199,31 @@ def test_largest_block_the_index_type_allows():
         ctx.dev_bwt_inverse(d_bwt, n, origin, d_back)
         assert torch.equal(d_back, d_in)
         print("n = 2^31 - 2: rounds", st["rounds"], "sort passes", st["sort_passes"], "sa ms", round(st["ms_sa"], 2))
+
+
+def test_suffix_array_above_2p27_entries():
+    """Blocks of more than 2^27 bytes on the suffix-array path: the rank array is built through LDS windows with a third split level (round 4;
+    it was the bucketed store).  Text with planted repeats, so that ranks are built and doubling runs: permutation, every neighbour in
+    order, and the BWT of the same block (the L-first way) inverts to the text."""
+    n = (1 << 27) + 4099
+    block = datagen.wiki_like(n, 77)
+    d_in = torch.from_numpy(block).cuda()
+    with dark_amd.Context(n) as ctx:
+        d_sa = torch.empty(n, dtype=torch.int32, device="cuda")
+        ctx.dev_suffix_array(d_in, n, d_sa)
+        assert "isa_windows" in ctx.stats()["routes"], ctx.stats()["routes"]
+        assert_permutation(d_sa, n)
+        assert_all_neighbours_in_order(d_in, d_sa, n, block)
+        # L from the suffix array, on the GPU, against the L-first path's
+        idx = (d_sa.to(torch.int64) & 0xFFFFFFFF) - 1
+        idx[idx < 0] = n - 1
+        want = d_in[idx]
+        del idx, d_sa
+        d_bwt = torch.empty(n, dtype=torch.uint8, device="cuda")
+        origin = ctx.dev_bwt_forward(d_in, n, d_bwt)
+        assert "lfirst" in ctx.stats()["routes"]
+        assert torch.equal(d_bwt, want)
+        del want
+        d_back = torch.empty(n, dtype=torch.uint8, device="cuda")
+        ctx.dev_bwt_inverse(d_bwt, n, origin, d_back)
+        assert torch.equal(d_back, d_in)
