@@ -26,6 +26,13 @@ def make_input(kind, n):
         return torch.from_numpy(datagen.wiki_like(n, 2)).cuda()
     if kind == "wordlike":  # the bench workload wordlike_1e8 at n = 1e8
         return torch.from_numpy(datagen.word_like(n, 5)).cuda()
+    if kind == "wordlike26":  # the 28-symbol variant (5-bit codes: eleven symbols in the initial key)
+        return torch.from_numpy(datagen.word_like(n, 6, alpha=26)).cuda()
+    if kind == "wordlike_big_vocab":  # 2 M words, Zipf 1.15: fewer repetitions of the frequent words' neighbourhoods
+        return torch.from_numpy(datagen.word_like(n, 7, vocab=2_000_000)).cuda()
+    if kind == "mixed":  # half Markov text, half word-like
+        import numpy as _np
+        return torch.from_numpy(_np.concatenate([datagen.wiki_like(n // 2, 2), datagen.word_like(n - n // 2, 5)])).cuda()
     if kind == "acgt":
         return torch.from_numpy(np.frombuffer(b"ACGT", np.uint8)).cuda()[torch.randint(0, 4, (n,), device="cuda", generator=g)]
     return torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda", generator=g)
