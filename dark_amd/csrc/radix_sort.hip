@@ -588,8 +588,10 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
     // the scatters 10 % slower (the plane's 16-byte runs cost as many L2 write requests as the 64-byte runs of the values).  Net gain,
     // round 3: 2.7 % of the whole suffix sort at 1e8 pairs (12.07 -> 11.74 ms), 1.8 % at 2^28; on from 2^26 pairs, where the keys
     // (8 bytes per pair) no longer fit the 256 MiB Infinity Cache.
-    const int plane_mode = DK_KNOB("DK_DIGIT_PLANE", -1);  // tuning build: 1 / 0 = always (from 2^20 pairs) / never
-    const size_t plane_from = plane_mode == 1 ? (size_t(1) << 20) : (size_t(1) << 26);
+    // Round 4: on from 2^20 pairs -- the big lists of the L-first path are 1 to 60 M pairs, sorted round after round: 1e8 bytes of word-like
+    // text 19.2 -> 18.3 ms (histograms 2.7 -> 1.6 ms, scatters 8.6 -> 8.8), the 1e8 text block 6.4 -> 6.25.
+    const int plane_mode = DK_KNOB("DK_DIGIT_PLANE", -1);  // tuning build: 1 / 0 = always (from 2^20 pairs) / never; 2 = from 2^26 (rounds 2-3)
+    const size_t plane_from = plane_mode == 2 ? (size_t(1) << 26) : (size_t(1) << 20);
     uint8_t *plane = plane_mode != 0 && end_bit - begin_bit > 8 && count >= plane_from ? ctx->ws_try_alloc<uint8_t>(count) : nullptr;  // optional: the sort runs without it
     if (!tile_pre || !chunk_sum || !digit_total) return DK_E_NOMEM;
     hipStream_t st = ctx->stream;

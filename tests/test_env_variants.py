@@ -3,7 +3,7 @@ the same bytes.
   DK_ENTROPY_THREADS=1|2|4  host coder: one thread, models | coder on two, the four-stage pipeline of the dark model (product library)
 The device-side switches exist in the TUNING build only (dark_amd/libdark_amd_tuning.so, -DDK_TUNING: csrc/context.hpp DK_KNOB); the
 product library has them compiled in as constants:
-  DK_XCD=0 plain tile order | DK_DIGIT_PLANE=1 histograms from the digit plane at every size | DK_PLATEAU=0 general doubling rounds only | DK_PAIR_CHAINS=0 no pair chains in front of the in-place rounds
+  DK_XCD=0 plain tile order | DK_DIGIT_PLANE=0 / 2 histograms from the keys always / from the digit plane from 2^26 pairs only | DK_PLATEAU=0 general doubling rounds only | DK_PAIR_CHAINS=0 no pair chains in front of the in-place rounds
   DK_BWT_CARRY=0 L gathered from the suffix array instead of riding with the suffixes | DK_PREFIX=0|1|2|3 prefix length of the initial sort"""
 import os
 import subprocess
@@ -153,7 +153,7 @@ def test_entropy_error_paths_return_codes(threads):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"DK_XCD": "0"}, {"DK_DIGIT_PLANE": "1"}, {"DK_PLATEAU": "0"}, {"DK_BWT_CARRY": "0"},
+@pytest.mark.parametrize("env", [{"DK_XCD": "0"}, {"DK_DIGIT_PLANE": "0"}, {"DK_DIGIT_PLANE": "2"}, {"DK_PLATEAU": "0"}, {"DK_BWT_CARRY": "0"},
                                  {"DK_PLATEAU": "0", "DK_BWT_CARRY": "0"}, {"DK_PAIR_CHAINS": "0"}, {"DK_PAIR_CHAINS": "1", "DK_BWT_CARRY": "0"},
                                  {"DK_LFIRST": "0"}, {"DK_LFIRST": "2"}, {"DK_LFIRST": "2", "DK_LF_MAX": "32"}, {"DK_LF_SWITCH": "40"},
                                  {"DK_LF_SWITCH": "100"}])
