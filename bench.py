@@ -34,7 +34,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="enwik8_like_1e8",
                     help="enwik8_like_1e8 (BASELINE configs[1], default) | book1_like_768771 | acgt_2p28 | enwik9_block_125e6 | random_2p30 | "
-                         "wordlike_1e8 (Zipf-word text with an 8-bit alphabet: what real text does to the suffix sort, tracked beside the headline)")
+                         "wordlike_1e8 (Zipf-word text with an 8-bit alphabet: what real text does to the suffix sort, tracked beside the headline) | "
+                         "realtext_5e7 (50 MB of the image's own text files -- Python sources, ROCm headers: the only real bytes on the box)")
     ap.add_argument("--n", type=int, default=0, help="override the block size (debug)")
     ap.add_argument("--model", default="dark")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -133,6 +134,7 @@ def make_block(workload, seed_offset, n_override):
         "enwik9_block_125e6": (datagen.wiki_like, 125_000_000, 40),
         "random_2p30": (datagen.random_bytes, 1 << 30, 50),
         "wordlike_1e8": (datagen.word_like, 100_000_000, 5),
+        "realtext_5e7": (datagen.real_text, 50_000_000, 0),
     }
     fn, n, seed = gens[workload]
     return fn(n, seed + seed_offset)
@@ -604,7 +606,7 @@ def main():
         result = {
             "metric": "bwt_encode_MBps", "value": round(world * n * k / elapsed_max / 1e6, 3), "unit": "MB/s",
             "n_gpus": world, "steps": k, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed_max / k, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64 integer", "data": "real" if corpus_path else "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64 integer", "data": "real" if corpus_path else ("real (text files of this image, datagen.real_text)" if args.workload == "realtext_5e7" and not args.n else "synthetic"),
             "config": {"workload": workload_name, "block_bytes": n, "model": args.model,
                        "blocks_per_gpu": 1, "parallelism": "block-per-gpu x%d" % world, "host_cpus_per_rank": share, "node_gpus": node_gpus,
                        "gather": args.gather if use_dist else "none"},

@@ -98,6 +98,40 @@ def word_like(n=100_000_000, seed=5, vocab=200_000, alpha=180):
     return out
 
 
+def real_text(n=50_000_000, seed=0, exts=(".py", ".pyi", ".txt", ".rst", ".md", ".h", ".hpp")):
+    """REAL text, the only kind the image holds (no book1 / enwik8, no network): the text files under the interpreter's library directories
+    and the ROCm headers, walked in sorted order and concatenated to n bytes -- words, indentation runs, licence boilerplate repeated hundreds of
+    times ("no real byte has been through the path").  Files with a byte 0xFF are left out (the reference format cannot
+    decode such a block, src/block/dc.rs:57-73).  The same image on the build container and on the GPU box gives the same bytes; `seed` rotates
+    the list of files.  Raises when the directories hold fewer than n bytes."""
+    import os
+    roots = [os.path.dirname(os.__file__), "/usr/local/lib/python3.10/dist-packages", "/usr/lib/python3/dist-packages", "/opt/rocm/include"]
+    paths = []
+    for root in roots:
+        for dirpath, dirnames, files in os.walk(root):
+            dirnames.sort()
+            paths += [os.path.join(dirpath, f) for f in sorted(files) if f.endswith(tuple(exts))]
+    if seed:
+        k = (seed * 7919) % max(1, len(paths))
+        paths = paths[k:] + paths[:k]
+    out, total = [], 0
+    for p in paths:
+        try:
+            with open(p, "rb") as fh:
+                b = fh.read()
+        except OSError:
+            continue
+        if not b or b"\xff" in b:
+            continue
+        out.append(b)
+        total += len(b)
+        if total >= n:
+            break
+    if total < n:
+        raise ValueError("real_text: the image holds %d bytes of text files, fewer than n = %d" % (total, n))
+    return np.frombuffer(b"".join(out)[:n], dtype=np.uint8).copy()
+
+
 WORKLOADS = {
     "book1_like_768771": lambda seed=1: english_like(768771, seed),
     "enwik8_like_1e8": lambda seed=2: wiki_like(100_000_000, seed),
@@ -105,4 +139,5 @@ WORKLOADS = {
     "enwik9_block_125e6": lambda seed=40: wiki_like(125_000_000, seed),
     "random_2p30": lambda seed=50: random_bytes(1 << 30, seed),
     "wordlike_1e8": lambda seed=5: word_like(100_000_000, seed),
+    "realtext_5e7": lambda seed=0: real_text(50_000_000, seed),
 }

@@ -18,6 +18,7 @@ SPECS = {
     "acgt_2p28": (lambda: datagen.acgt(1 << 28, 3), True),
     "random_2p30": (lambda: datagen.random_bytes(1 << 30, 50), True),
     "wordlike_1e8": (lambda: datagen.word_like(100_000_000, 5), True),
+    "realtext_5e7": (lambda: datagen.real_text(50_000_000, 0), True),  # real bytes: the image's own text files (no corpus is on disk)
 }
 # small stand-ins with the same code path, for checking this module itself on the CPU (tests/test_oracle.py)
 SPECS_SMALL = {

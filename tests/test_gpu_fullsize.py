@@ -93,7 +93,7 @@ def host_equal(d_tensor, want, what):
         raise AssertionError("%s: %d mismatches, first at %d: got %s want %s" % (what, len(bad), bad[0], got[bad[0]:bad[0] + 8], want[bad[0]:bad[0] + 8]))
 
 
-@pytest.mark.parametrize("workload", ["enwik8_like_1e8", "wordlike_1e8", "enwik9_block_125e6", "acgt_2p28", "random_2p30"])
+@pytest.mark.parametrize("workload", ["enwik8_like_1e8", "wordlike_1e8", "realtext_5e7", "enwik9_block_125e6", "acgt_2p28", "random_2p30"])
 def test_fullsize_stream_equals_oracle(orc, workload):
     job = oracle_jobs.get(workload)  # joins the background run started at session begin
     block, want = job["block"], job["dc"]
