@@ -49,6 +49,7 @@ enum KernelSlot : int {
     K_ISA_PARTITION,       // k_isa_init + k_isa_split<true> + k_isa_split<false> (inverse permutation through LDS windows)
     K_ISA_ASSEMBLE,        // k_isa_assemble
     K_CHAIN,               // k_chain_extract + _ends + _tiles + _spine + _verdicts + _apply (pair chains; their sort is in the radix slots)
+    K_PERIOD,              // k_period_first + _spine + _fill (next break of the block's dominant period, for the period round)
     K_SLOT_COUNT
 };
 static_assert(K_SLOT_COUNT <= DK_NUM_KERNEL_SLOTS, "grow DK_NUM_KERNEL_SLOTS");

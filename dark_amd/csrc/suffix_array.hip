@@ -92,6 +92,126 @@ __global__ __launch_bounds__(256) void k_run_probe(const uint8_t *__restrict__ t
     if ((threadIdx.x & 63) == 0 && pieces) atomicAdd(&flag[1], pieces);
 }
 
+// ---- periodic stretches (runs of one byte value are period 1) ---------------------------------------------------------------------
+// The suffixes inside a stretch of period p (T[j] == T[j+p] over a long range: zero padding, a^n, (ab)^n, arrays of one 32-bit value) are what
+// prefix doubling is slowest on: they stay one group until the depth reaches the stretch's length, log2(length) rounds over all of them.  But
+// their order follows from where the stretch ENDS: two suffixes x, y equal in their first h >= p symbols and p-periodic that far are
+// ordered by e = LCE(x, x + p) and by how the shorter stretch breaks -- if e(x) < e(y), y still follows the period where x breaks it, so
+// x < y exactly when x's breaking symbol T[x + e + p] is smaller than the symbol the period asks for there, T[x + e] (or the text ends).
+// One round with the token (direction, e or its complement, the bytes from the break on) as secondary key settles them all (k_round_local).
+// k_period_probe counts, for p = 1..8, the aligned 64-byte windows that follow period p; k_period_first / _spine / _fill give every position
+// its next break: nb[i] = min { j >= i : j + p >= n or T[j] != T[j+p] }.
+__global__ __launch_bounds__(256) void k_period_probe(const uint8_t *__restrict__ t, size_t n, uint32_t *__restrict__ counts) {
+    const size_t w = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t p0 = w * 64;
+    uint32_t ok = 0;  // bit p-1: the window follows period p
+    if (p0 + 72 <= n && (reinterpret_cast<uintptr_t>(t) & 7) == 0) {
+        const uint64_t *q = reinterpret_cast<const uint64_t *>(t + p0);
+        uint64_t v[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = q[k];
+        ok = 0xFFu;
+#pragma unroll
+        for (int p = 1; p <= 8; ++p) {
+            uint64_t diff = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) diff |= v[k] ^ (p == 8 ? v[k + 1] : ((v[k] >> (8 * p)) | (v[k + 1] << (64 - 8 * (p & 7)))));
+            if (diff) ok &= ~(1u << (p - 1));
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const uint32_t c = static_cast<uint32_t>(__popcll(__ballot((ok >> p) & 1u)));
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&counts[p], c);
+    }
+}
+
+constexpr int PB_TILE = 4096;  // positions per workgroup: 256 threads x 16
+// sixteen bytes from position j on (zero past the end) as two little-endian words
+__device__ __forceinline__ void load16_le(const uint8_t *__restrict__ t, size_t n, size_t j, uint64_t *lo, uint64_t *hi) {
+    if (j + 16 <= n && ((reinterpret_cast<uintptr_t>(t) + j) & 15) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(t + j);
+        *lo = (static_cast<uint64_t>(v.y) << 32) | v.x;
+        *hi = (static_cast<uint64_t>(v.w) << 32) | v.z;
+        return;
+    }
+    uint64_t a = 0, b = 0;
+    for (int k = 0; k < 8; ++k) {
+        a |= static_cast<uint64_t>(j + k < n ? t[j + k] : 0u) << (8 * k);
+        b |= static_cast<uint64_t>(j + 8 + k < n ? t[j + 8 + k] : 0u) << (8 * k);
+    }
+    *lo = a;
+    *hi = b;
+}
+// bit k of the result: position j + k is a break (T[j+k] != T[j+k+p], or j + k + p >= n); positions at or beyond n are breaks too
+__device__ __forceinline__ uint32_t period_breaks16(const uint8_t *__restrict__ t, size_t n, size_t j, int p) {
+    uint64_t w0, w1, w2, w3;
+    load16_le(t, n, j, &w0, &w1);
+    load16_le(t, n, j + 16, &w2, &w3);
+    (void)w3;
+    const uint64_t s0 = p == 8 ? w1 : ((w0 >> (8 * p)) | (w1 << (64 - 8 * (p & 7))));
+    const uint64_t s1 = p == 8 ? w2 : ((w1 >> (8 * p)) | (w2 << (64 - 8 * (p & 7))));
+    const uint64_t x0 = w0 ^ s0, x1 = w1 ^ s1;
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        m |= ((x0 >> (8 * k)) & 0xFFu) ? (1u << k) : 0u;
+        m |= ((x1 >> (8 * k)) & 0xFFu) ? (1u << (8 + k)) : 0u;
+    }
+    // the text's end: every j' with j' + p >= n breaks
+    const size_t lim = n >= static_cast<size_t>(p) ? n - p : 0;  // first such position
+    if (j + 16 > lim) m |= lim > j ? (0xFFFFu << (lim - j)) & 0xFFFFu : 0xFFFFu;
+    return m;
+}
+constexpr uint32_t PB_NONE = 0xFFFFFFFFu;
+// thread tid takes the tile's chunk 255 - tid: an exclusive running max over the threads in tid order then covers the chunks BEHIND its own
+__global__ __launch_bounds__(256) void k_period_first(const uint8_t *__restrict__ t, uint32_t n, int p, uint32_t *__restrict__ tile_first) {
+    __shared__ uint32_t s_tmp[4 + 1];
+    const size_t j = static_cast<size_t>(blockIdx.x) * PB_TILE + static_cast<size_t>(255 - threadIdx.x) * 16;
+    const uint32_t m = j < n ? period_breaks16(t, n, j, p) : 0xFFFFu;
+    const uint32_t first = m ? static_cast<uint32_t>(j) + static_cast<uint32_t>(__builtin_ctz(m)) : PB_NONE;
+    uint32_t total = 0;
+    (void)block_excl_max<4>(PB_NONE - first, s_tmp, &total);
+    if (threadIdx.x == 0) tile_first[blockIdx.x] = PB_NONE - total;
+}
+// tile_first[b] -> first break in the tiles behind b (PB_NONE: none)
+__global__ __launch_bounds__(1024) void k_period_spine(uint32_t *__restrict__ tile_first, size_t ntiles) {
+    __shared__ uint32_t s_tmp[16 + 1];
+    const size_t per = (ntiles + 1023) / 1024;
+    const size_t c = 1023 - threadIdx.x;  // chunk of tiles, taken in reverse like the positions of a tile
+    const size_t b0 = c * per < ntiles ? c * per : ntiles, b1 = b0 + per < ntiles ? b0 + per : ntiles;
+    uint32_t first = PB_NONE;
+    for (size_t b = b1; b > b0; --b) first = tile_first[b - 1] != PB_NONE ? tile_first[b - 1] : first;
+    uint32_t behind = PB_NONE - block_excl_max<16>(PB_NONE - first, s_tmp, nullptr);
+    for (size_t b = b1; b > b0; --b) {
+        const uint32_t v = tile_first[b - 1];
+        tile_first[b - 1] = behind;
+        if (v != PB_NONE) behind = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_period_fill(const uint8_t *__restrict__ t, uint32_t n, int p, const uint32_t *__restrict__ tile_behind,
+                                                     uint32_t *__restrict__ nb) {
+    __shared__ uint32_t s_tmp[4 + 1];
+    const size_t j = static_cast<size_t>(blockIdx.x) * PB_TILE + static_cast<size_t>(255 - threadIdx.x) * 16;
+    const uint32_t m = j < n ? period_breaks16(t, n, j, p) : 0xFFFFu;
+    const uint32_t first = m ? static_cast<uint32_t>(j) + static_cast<uint32_t>(__builtin_ctz(m)) : PB_NONE;
+    uint32_t next = PB_NONE - block_excl_max<4>(PB_NONE - first, s_tmp, nullptr);  // first break in the tile's chunks behind mine
+    if (next == PB_NONE) next = tile_behind[blockIdx.x];
+    if (j >= n) return;
+    uint32_t out[16];
+#pragma unroll
+    for (int k = 15; k >= 0; --k) {
+        if ((m >> k) & 1u) next = static_cast<uint32_t>(j) + static_cast<uint32_t>(k);
+        out[k] = next;
+    }
+    if (j + 16 <= n) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) reinterpret_cast<uint4 *>(nb + j)[k] = make_uint4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+    } else {
+        for (int k = 0; k < 16 && j + k < n; ++k) nb[j + k] = out[k];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_sa_descending(uint32_t *__restrict__ sa, size_t n) {
     const size_t j = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (j < n) sa[j] = static_cast<uint32_t>(n - 1 - j);
@@ -800,7 +920,9 @@ __device__ __forceinline__ uint32_t rank2_of(const uint32_t *__restrict__ rank, 
 // bits == 0: RAW mode -- the key is the next eight BYTES of the text, big-endian (the byte order is the symbol order, so no code table
 // is needed; one or two aligned 8-byte loads per suffix).  Otherwise tsym symbols through the code table (small alphabets: more
 // symbols per 64 bits), the table staged in LDS.
-struct TextSource { const uint8_t *text; const uint8_t *code; int bits; int tsym; };
+// next_break != nullptr (raw mode only): the period round -- a suffix that follows period `period` through the depth reached so far takes the token
+// of its stretch's end as secondary key instead of the next eight bytes (k_period_fill; ebits = bits that hold any length up to n)
+struct TextSource { const uint8_t *text; const uint8_t *code; int bits; int tsym; const uint32_t *next_break; int period; int ebits; };
 
 // bytes T[p .. p+8) as a big-endian integer, zero padded past the end of the text.  One 8-byte load at the byte address itself (the
 // hardware takes unaligned global addresses; two aligned loads and a funnel shift were twice the requests for the same line).
@@ -864,6 +986,18 @@ __global__ __launch_bounds__(LS_BLOCK) void k_round_local(const uint32_t *__rest
     auto second = [&](uint32_t suffix) -> R2 {
         if (TEXT) {
             const size_t p = static_cast<size_t>(suffix) + h;
+            if (ts.next_break && p <= n) {
+                // all members of a group agree on this test (it reads their first h symbols only); a suffix shorter than h keeps the text key
+                // (zero: it ends first) and so sorts in front of its group, where a proper prefix of the others belongs
+                const uint32_t b = ts.next_break[suffix], e = b - suffix;  // T[suffix + k] == T[suffix + k + period] for k < e
+                if (e + static_cast<uint32_t>(ts.period) >= h) {
+                    const size_t brk = static_cast<size_t>(b) + ts.period;  // the first symbol that does not follow the period (<= n)
+                    const bool down = brk >= n || ts.text[brk] < ts.text[b];
+                    const uint64_t ev = down ? e : ((1u << ts.ebits) - 1u - e);
+                    const uint64_t tail = text_key_raw(ts.text, n, brk) >> 32;  // four bytes from the break on
+                    return static_cast<R2>((static_cast<uint64_t>(down ? 0u : 1u) << 63) | (ev << (63 - ts.ebits)) | (tail << (31 - ts.ebits)));
+                }
+            }
             return static_cast<R2>(ts.bits ? text_key_coded(ts.text, n, s_code, p, ts.bits, ts.tsym) : text_key_raw(ts.text, n, p));
         }
         return static_cast<R2>(rank2_of(rank, suffix, n, h));
@@ -1362,14 +1496,16 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
 
     // 1. alphabet
     uint32_t *d_hist = ctx->d_mail + 16;
-    DK_HIP(ctx, hipMemsetAsync(d_hist, 0, 258 * sizeof(uint32_t), st));  // (+ the run probe's two words behind the 256 counters)
+    DK_HIP(ctx, hipMemsetAsync(d_hist, 0, 266 * sizeof(uint32_t), st));  // (+ the run probe's two words and the period probe's eight behind the 256 counters)
+    const int period_mode = DK_KNOB("DK_PERIOD", 1);  // 0 = never a period round, 1 = where the probe finds an eighth of the block periodic, 2 = wherever it finds a window (test hook)
     {
         LaunchScope ls(ctx, K_SYM_HIST, 1.0 * n);
         const size_t blocks = std::min<size_t>(div_up(n, 256 * 64), 2048);
         k_sym_hist<<<dim3(blocks), dim3(256), 0, st>>>(d_text, n, d_hist);
         if (d_bwt && allow_lfirst && n >= (1u << 16)) k_run_probe<<<dim3(div_up(div_up(n, 256), 256)), dim3(256), 0, st>>>(d_text, n, d_hist + 256);
+        if (period_mode != 0 && n >= (1u << 12)) k_period_probe<<<dim3(div_up(div_up(n, 64), 256)), dim3(256), 0, st>>>(d_text, n, d_hist + 258);
     }
-    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 16, d_hist, 258 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 16, d_hist, 266 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     DK_HIP(ctx, hipStreamSynchronize(st));
     // a run of 511 bytes, or more than 1 % of the block's 16-byte pieces inside runs: not the L-first path's kind of block
     const bool long_run = ctx->h_mail[16 + 256] != 0 || static_cast<double>(ctx->h_mail[16 + 257]) * 16.0 > 0.01 * static_cast<double>(n);
@@ -1528,13 +1664,24 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
     // one general round: secondary keys (ranks h further on, or the next tsym symbols of the text) -> every group sorted inside its
     // own slot range (small groups in LDS, big ones through the global sort) -> rerank.  Returns the symbols the round added (text
     // rounds: the big groups' keys may hold fewer symbols than the small groups' -- the depth every group is known to is the smaller).
-    auto run_round = [&](int tsym, int *advanced) -> int {
+    auto run_round = [&](int tsym, int *advanced, int period = 0, const uint32_t *next_break = nullptr) -> int {
         const uint32_t h_eff = static_cast<uint32_t>(std::min<uint64_t>(h, n));
         const int bsbits = nbiggroups > 1 ? static_cast<int>(ceil_log2_u64(nbiggroups)) : 1;  // bits of a big group's dense index
         int kbits, kb;
-        const bool raw_text = tsym > 0 && bits >= 5;  // eight raw bytes per key beat the code table unless the alphabet is small
+        const bool raw_text = tsym > 0 && (bits >= 5 || period > 0);  // eight raw bytes per key beat the code table unless the alphabet is small
         const int tbits = raw_text ? 8 : bits;
-        if (tsym > 0) {
+        const int ebits = static_cast<int>(ceil_log2_u64(static_cast<uint64_t>(n) + 1));
+        if (period > 0) {
+            // the period round: tokens (direction, length to the break, bytes from the break on) in 64-bit keys; the big list takes their
+            // leading bits down to the first byte behind the break when the symbol in front still fits below them, else what fits.  The depth
+            // every group is known to stays h: equal tokens say "equal up to the break" and the break may come right behind h.
+            tsym = 8;
+            kbits = 64;
+            kb = 1 + ebits + 8;
+            if (kb + bsbits + 8 > 64) kb = std::max(1 + ebits, 56 - bsbits);
+            if (kb + bsbits > 63) kb = 63 - bsbits;
+            if (advanced) *advanced = 0;
+        } else if (tsym > 0) {
             if (raw_text) tsym = 8;
             kbits = tsym * tbits;
             // the big list's key: (offset in the big list) above the leading symbols of the secondary key -- at most 32 bits of it: every
@@ -1545,8 +1692,8 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
         } else {
             kbits = kb = static_cast<int>(ceil_log2_u64(static_cast<uint64_t>(n) + h_eff));
         }
-        const TextSource ts{d_text, d_code, raw_text ? 0 : bits, tsym};
-        route |= tsym > 0 ? DK_ROUTE_TEXT_ROUND : DK_ROUTE_GENERAL_ROUND;
+        const TextSource ts{d_text, d_code, raw_text ? 0 : bits, tsym, period > 0 ? next_break : nullptr, period, ebits};
+        route |= period > 0 ? DK_ROUTE_PERIOD_ROUND : tsym > 0 ? DK_ROUTE_TEXT_ROUND : DK_ROUTE_GENERAL_ROUND;
         if (nbig > 0) route |= DK_ROUTE_BIG_GROUPS;
         const int big_carry = carry_bwt && kb + bsbits + 8 <= 64 ? 1 : 0;  // the big list's keys have room for the symbol in front
         uint32_t *bslot = pos_alt;  // written by the rerank at the end of the round only: free until k_big_back has read it
@@ -1583,7 +1730,7 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
         std::swap(gid, gid_alt);
         if (trace)
             fprintf(stderr, "[dk] round %u h=%llu%s slots=%zu big=%zu key bits=%d (big %d+%d) -> active=%zu groups=%zu big=%zu (>%d: %zu)\n", ctx->stats.rounds,
-                    (unsigned long long)h, tsym > 0 ? " (text)" : "", active, nbig, kbits, bsbits, kb, next_active, next_groups, next_big, PL_MAX, next_medium);
+                    (unsigned long long)h, period > 0 ? " (period tokens)" : tsym > 0 ? " (text)" : "", active, nbig, kbits, bsbits, kb, next_active, next_groups, next_big, PL_MAX, next_medium);
         active = next_active;
         groups = next_groups;
         nbig = next_big;
@@ -1630,6 +1777,38 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
         }                                                                                                                   \
     } while (0)
 
+    // 4b. the period round (see k_period_probe): where an eighth of the block lies in stretches of one period p <= 8 (and p <= h: the members
+    //     of a group must share the period string itself), every suffix inside such a stretch is placed by where the stretch ends -- a^n b,
+    //     (ab)^n, zero padding: one round instead of log2(length) doubling rounds over all of them.  The rank array's buffer holds the
+    //     next-break positions (it is built later).
+    if (active > 0 && period_mode != 0) {
+        const uint32_t *pc = ctx->h_mail + 16 + 258;
+        const int pmax = static_cast<int>(std::min<uint64_t>(8, h));
+        uint32_t cmax = 0;
+        for (int q = 1; q <= pmax; ++q) cmax = std::max(cmax, pc[q - 1]);
+        int period = 0;
+        if (cmax > 0 && (period_mode == 2 || static_cast<uint64_t>(cmax) * 64 * 8 >= n))
+            for (int q = 1; q <= pmax && !period; ++q)
+                if (static_cast<uint64_t>(pc[q - 1]) * 10 >= static_cast<uint64_t>(cmax) * 9) period = q;
+        if (period) {
+            const size_t ptiles = div_up(n, PB_TILE);
+            const size_t mark2 = ctx->ws_mark();
+            uint32_t *tile_first = ctx->ws_alloc<uint32_t>(ptiles);
+            if (!tile_first) return DK_E_NOMEM;
+            {
+                LaunchScope ls(ctx, K_PERIOD, 2.0 * n + 4.0 * n);
+                k_period_first<<<dim3(ptiles), dim3(256), 0, st>>>(d_text, static_cast<uint32_t>(n), period, tile_first);
+                k_period_spine<<<dim3(1), dim3(1024), 0, st>>>(tile_first, ptiles);
+                k_period_fill<<<dim3(ptiles), dim3(256), 0, st>>>(d_text, static_cast<uint32_t>(n), period, tile_first, rank);
+            }
+            DK_HIP(ctx, hipGetLastError());
+            if (trace)
+                fprintf(stderr, "[dk] period probe: 64-byte windows of period 1..8: %u %u %u %u %u %u %u %u of %zu -> period %d\n", pc[0], pc[1], pc[2], pc[3], pc[4], pc[5],
+                        pc[6], pc[7], n / 64, period);
+            DK_TRY(run_round(8, nullptr, period, rank));
+            ctx->ws_release(mark2);
+        }
+    }
     // 5a. extend the survivors' keys from the text: up to floor(63 / bits) further symbols per round, no ranks needed.  A second
     //     such round only when the first left a lot (otherwise what is left are long repeats, which want doubling).
     for (int t = 0; !have_ranks && active > 0 && t < 2; ++t) {

@@ -4,7 +4,8 @@ the same bytes.
 The device-side switches exist in the TUNING build only (dark_amd/libdark_amd_tuning.so, -DDK_TUNING: csrc/context.hpp DK_KNOB); the
 product library has them compiled in as constants:
   DK_XCD=0 plain tile order | DK_DIGIT_PLANE=0 / 2 histograms from the keys always / from the digit plane from 2^26 pairs only | DK_PLATEAU=0 general doubling rounds only | DK_PAIR_CHAINS=0 no pair chains in front of the in-place rounds
-  DK_BWT_CARRY=0 L gathered from the suffix array instead of riding with the suffixes | DK_PREFIX=0|1|2|3 prefix length of the initial sort"""
+  DK_BWT_CARRY=0 L gathered from the suffix array instead of riding with the suffixes | DK_PREFIX=0|1|2|3 prefix length of the initial sort
+  DK_PERIOD=0 never a period round | 2 a period round wherever the probe finds one periodic 64-byte window (the product asks for an eighth of the block)"""
 import os
 import subprocess
 import sys
@@ -172,3 +173,21 @@ def test_gpu_prefix_paths_match_oracle(mode):
 def test_gpu_prefix_paths_with_lfirst_forced(mode):
     """the L-first BWT path behind shortened (and narrow) keys, which the product never takes (csrc/suffix_array.hip: nothing survives such a sort)"""
     _run(PREFIX_SNIPPET, {"DK_PREFIX": mode, "DK_LFIRST": "2"}, tuning=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"DK_PERIOD": "0"}, {"DK_PERIOD": "1"}, {"DK_PERIOD": "2"}, {"DK_PERIOD": "2", "DK_PREFIX": "2"},
+                                 {"DK_PERIOD": "2", "DK_BWT_CARRY": "0"}, {"DK_PERIOD": "2", "DK_LFIRST": "0"}])
+def test_gpu_period_round_variants(env):
+    """runs, stretches of period 1..8 with ties between them, whole-block periods with one odd byte, blocks ending inside a run
+    (tools/period_check.py): suffix array, BWT and origin against the oracle with the period round off, as the product decides, and forced
+    -- also behind a four-symbol initial sort (periods above four are then out of reach) and with L gathered from the suffix array"""
+    e = dict(os.environ)
+    e.update(env)
+    e["DARK_AMD_LIB"] = TUNING_LIB
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "period_check.py"), "3", "15"], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "wrong results: 0" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+    if env == {"DK_PERIOD": "0"}:
+        assert "period_round" not in out.stdout
+    else:
+        assert "period_round" in out.stdout

@@ -53,18 +53,19 @@ def test_sort_pairs(ctx):
 
 def test_five_megabyte_blocks(orc):
     """blocks above 2^22 bytes: the prefix probe picks the key length and the rank array is built through LDS windows -- text, {A,C,G,T},
-    random bytes, a period-2 block and two identical halves"""
+    random bytes, a period-2 block, two identical halves and a period-12 block"""
     from dark_amd import datagen
     rng = np.random.default_rng(3)
     n = 5_000_011
     cases = [datagen.wiki_like(n, 7), datagen.acgt(n, 8), datagen.random_bytes(n, 9), np.frombuffer(b"ab" * (n // 2) + b"a", np.uint8),
-             np.concatenate([datagen.wiki_like(n // 2, 10)] * 2)]
+             np.concatenate([datagen.wiki_like(n // 2, 10)] * 2), np.frombuffer(b"abcdefghijkl" * (n // 12), np.uint8)]
     # what each case must have gone through: (suffix array call, BWT call)
     routes = [({"isa_windows", "text_round", "inplace_rounds", "pair_chains"}, {"lfirst", "lfirst_deep"}),   # text: long repeats end as pair chains / deep groups
               ({"short_prefix", "narrow_keys", "text_round"}, {"short_prefix", "narrow_keys"}),              # {A,C,G,T}: the probe shortens the key
               ({"short_prefix", "narrow_keys"}, {"short_prefix", "narrow_keys"}),                            # random bytes
-              ({"isa_windows", "isa_marked", "general_round", "big_groups"}, {"general_round"}),              # period 2: giant groups
-              ({"isa_windows", "inplace_rounds"}, {"lfirst", "lfirst_deep"})]                                 # two identical halves
+              ({"period_round", "big_groups"}, {"period_round"}),                                             # period 2: one round on the tokens of the stretch's end
+              ({"isa_windows", "inplace_rounds"}, {"lfirst", "lfirst_deep"}),                                 # two identical halves
+              ({"isa_windows", "isa_marked", "general_round", "big_groups"}, {"general_round"})]              # period 12 (longer than the period round looks): giant groups, doubling
     with dark_amd.Context(n) as c:
         for t, (sa_route, bwt_route) in zip(cases, routes):
             t = np.ascontiguousarray(t)
@@ -583,3 +584,28 @@ def test_workspace_accounting(orc):
             st = c.stats()
             assert 0 < st["ws_peak_bytes"] <= st["ws_size_bytes"]
             print("n=%d peak %.1f n of %.1f n" % (len(t), st["ws_peak_bytes"] / len(t), st["ws_size_bytes"] / len(t)))
+
+
+def test_period_round_settles_periodic_blocks_in_one_round(orc):
+    """a^n b, (ab)^n, (abc)^n with one odd byte, 32-bit words of one value with one odd word: every suffix lies inside a stretch of one short
+    period, and one round on the tokens of the stretch's end (direction, length to the break) settles all of them -- the reference's SA-IS is
+    linear on such input (README.md:12), prefix doubling alone needs log2(n) rounds over everything (missing 4)"""
+    n = 3_000_001
+    abc = np.frombuffer(b"abc" * (n // 3 + 1), np.uint8)[:n].copy()
+    abc[n // 2] = ord("b")
+    words = np.tile(np.array([0, 0, 1, 7], np.uint8), n // 4 + 1)[:n].copy()
+    words[123_456] = 9
+    cases = {"a^n b": np.concatenate([np.zeros(n - 1, np.uint8), np.ones(1, np.uint8)]), "(ab)^n": np.frombuffer(b"ab" * (n // 2), np.uint8),
+             "b^n a": np.concatenate([np.full(n - 1, 98, np.uint8), np.full(1, 97, np.uint8)]), "(abc)^n, one odd byte": abc, "words, one odd": words}
+    with dark_amd.Context(n) as c:
+        for name, t in cases.items():
+            t = np.ascontiguousarray(t)
+            want = orc.sa_sais(t)
+            got = c.suffix_array(t)
+            assert first_diff(got, want) is None, (name, first_diff(got, want))
+            st = c.stats()
+            assert "period_round" in st["routes"] and st["rounds"] <= 3, (name, st["rounds"], st["routes"])
+            wb, wo = orc.bwt_forward(t, want)
+            bwt, origin = c.bwt_forward(t)
+            assert origin == wo and first_diff(bwt, wb) is None, name
+            assert "period_round" in c.stats()["routes"], (name, c.stats()["routes"])
