@@ -1509,6 +1509,9 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
     DK_HIP(ctx, hipStreamSynchronize(st));
     // a run of 511 bytes, or more than 1 % of the block's 16-byte pieces inside runs: not the L-first path's kind of block
     const bool long_run = ctx->h_mail[16 + 256] != 0 || static_cast<double>(ctx->h_mail[16 + 257]) * 16.0 > 0.01 * static_cast<double>(n);
+    // ... but a block with a few long runs and next to nothing else inside runs (a zero-padded header in front of text) stays with it: the run's
+    // suffixes ride in the big list until the round stalls, and one token round (k_lf_tokens) places them by where the run ends
+    const bool run_heavy = static_cast<double>(ctx->h_mail[16 + 257]) * 16.0 > 0.01 * static_cast<double>(n);
     uint8_t code[256];
     unsigned sigma = 0;
     for (int s = 0; s < 256; ++s) {
@@ -1629,17 +1632,29 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
     // Not where the probe saw more than 60 % of its sample in big groups (lfirst_path would find the same after a rerank, see there), not
     // where runs of one byte value are common (k_run_probe), and not behind a shortened key: next to nothing survives such a sort, and the uniformity test costs the first rerank more than it saves
     // (2^30 random bytes: reduce 2.3 against 1.1 ms, nothing else differs; 2^28 {A,C,G,T}: 8.63 against 8.56 ms).
-    if (carry_bwt && allow_lfirst && lf_mode != 0 && (lf_mode == 2 || (n >= (1u << 16) && probe_big_share <= 0.6 && !short_prefix && !long_run))) {
+    // the block's dominant short period, if it has any periodic 64-byte window at all (k_period_probe): the smallest p with nearly the most windows
+    int lf_period = 0;
+    if (period_mode != 0) {
+        const uint32_t *pc = ctx->h_mail + 16 + 258;
+        uint32_t cmax = 0;
+        for (int q = 1; q <= 7; ++q) cmax = std::max(cmax, pc[q - 1]);
+        for (int q = 1; q <= 7 && cmax > 0 && !lf_period; ++q)
+            if (static_cast<uint64_t>(pc[q - 1]) * 10 >= static_cast<uint64_t>(cmax) * 9) lf_period = q;
+    }
+    const bool lf_runs_ok = lf_period > 0 ? !run_heavy : !long_run;
+    if (carry_bwt && allow_lfirst && lf_mode != 0 && (lf_mode == 2 || (n >= (1u << 16) && probe_big_share <= 0.6 && !short_prefix && lf_runs_ok))) {
         const LfBuffers b{keys_alt, keys_3, vals_3, vals, rank, sym_alt, vals_alt, pos, gid, sym, gstart, bigidx, bigoff};
         bool done = false, pristine = true;
         route |= DK_ROUTE_LFIRST;
-        DK_TRY(lfirst_path(ctx, d_text, n, keys, key_shift, narrow_keys ? d_starts : nullptr, d_sa, d_bwt, d_origin, b, static_cast<uint32_t>(spk_sort), trace, lf_mode == 2, &done, &pristine));
+        // (the initial keys are read by the first rerank only: their buffer holds the next-break positions of a token round later)
+        DK_TRY(lfirst_path(ctx, d_text, n, keys, key_shift, narrow_keys ? d_starts : nullptr, d_sa, d_bwt, d_origin, b, static_cast<uint32_t>(spk_sort), trace, lf_mode == 2, &done, &pristine,
+                           nullptr, lf_period, reinterpret_cast<uint32_t *>(keys)));
         if (done) {
             ctx->ws_release(mark);
             *bwt_written = true;
             return DK_OK;
         }
-        route = (route & ~static_cast<uint32_t>(DK_ROUTE_LFIRST | DK_ROUTE_LFIRST_BIG_ROUND | DK_ROUTE_LFIRST_DEEP)) | DK_ROUTE_LFIRST_FALLBACK;
+        route = (route & ~static_cast<uint32_t>(DK_ROUTE_LFIRST | DK_ROUTE_LFIRST_BIG_ROUND | DK_ROUTE_LFIRST_DEEP | DK_ROUTE_PERIOD_ROUND)) | DK_ROUTE_LFIRST_FALLBACK;
         if (!pristine) {  // it gave up half way (L has been written to): the suffix-array path, from the start
             ctx->ws_release(mark);
             return suffix_array_impl(ctx, d_text, n, d_sa, d_bwt, d_origin, bwt_written, false);

@@ -526,8 +526,17 @@ def test_lfirst_bwt_without_the_suffix_array(orc):
     t = np.concatenate([base[:1_500_000], np.zeros(9, np.uint8)])
     cases.append(("ends in a few zeros", t, {"lfirst"}))
     t = base[:1_000_000].copy()
-    t[300_000:300_000 + 5000] = 65  # a run of 5000 equal bytes: one group that never splits on text -- seen by the run probe, suffix-array path
-    cases.append(("a run inside text", t, {"general_round"}))
+    t[300_000:300_000 + 5000] = 65  # a run of 5000 equal bytes: one group that never splits on text -- it rides in the big list until the round
+    cases.append(("a run inside text", t, {"lfirst", "lfirst_big_round", "period_round"}))  # stalls, then one token round places it by where the run ends
+    t = base[:1_000_000].copy()
+    for o in range(0, 900_000, 30_000):  # thirty runs of 700 bytes, 2 % of the block: more than the L-first path takes (run probe): suffix-array path
+        t[o + 100:o + 800] = 65
+    cases.append(("many runs inside text", t, {"general_round"}))
+    t = base[:1_000_000].copy()
+    for k, o in enumerate(range(0, 900_000, 100_000)):  # nine runs of the same length with the same byte behind them: the tokens tie, the rounds go on
+        t[o + 100:o + 500] = 66
+        t[o + 500] = 67
+    cases.append(("runs of one length inside text", t, {"lfirst", "period_round"}))
     t = base[:1_000_000].copy()
     t[300_033:300_033 + 300] = 65   # a run the probe does not see (it starts one byte behind a 256-byte border): a group of ~290 members that does not
     cases.append(("a short run inside text", t, {"lfirst", "lfirst_big_round", "lfirst_deep"}))  # split on text -- k_lf_deep orders it by common extensions
