@@ -33,6 +33,9 @@ constexpr int RS_BLOCK = DK_RS_BLOCK;        // threads per workgroup.  512 (819
                                              // in round 2: no faster on uniform digits (ACGT 8.9 ms either way), slower on text (5.5
                                              // against 4.3 ms) -- the scatter is not short of coalescing, it sits at 76 % of the copy rate
 constexpr int RS_WAVES = RS_BLOCK / 64;
+#ifndef DK_SCATTER_BLOCK_DEFAULT
+#define DK_SCATTER_BLOCK_DEFAULT 256
+#endif
 constexpr int RS_KPT = 16;                   // pairs per thread
 constexpr int RS_TILE = RS_BLOCK * RS_KPT;   // 4096 pairs per workgroup
 
@@ -324,26 +327,29 @@ struct TileOffsets { const uint32_t *tile_pre; const uint32_t *chunk_base; uint3
 // merges the short output runs of neighbouring tiles before it has to evict them (measured, 1e8 text: 3.95 ms of scatter per sort
 // against 3.6 ms; two per CU: 3.65 ms but slower overall).  The kernel is bound by that, not by its ballots: a third fewer vector
 // instructions in the ranking (wave_match) did not move it.
-template <bool PAIRS = false, bool TEXT = false>
-__global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_radix_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+// BLOCK threads share the tile of RS_TILE pairs: 256 threads with 16 pairs each (three waves per SIMD), or 512 with 8 (six: DK_SCATTER_BLOCK)
+template <bool PAIRS = false, bool TEXT = false, int BLOCK = RS_BLOCK>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3 * BLOCK / 256, 3 * BLOCK / 256))) void k_radix_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                              const uint32_t *__restrict__ pair_lo,
                                                              uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n,
                                                              int shift, TileOffsets offs, uint32_t xcd_tiles,
                                                              TextKeys tk, uint8_t *__restrict__ next_digit, SortFinalOut fin) {
+    constexpr int WAVES = BLOCK / 64, KPT = RS_TILE / BLOCK;
+    static_assert(!TEXT || BLOCK == RS_BLOCK, "the text pass builds its keys with RS_BLOCK threads");
     __shared__ uint64_t s_keys[RS_TILE];          // tile of keys in digit order; reused for the values
     // per-wave digit counters (then exclusive over waves) | tile-local start of each digit | global offset of the digit minus its
     // tile-local start.  TEXT: the same 6 KiB first hold the staged codes of the tile (the counters are cleared afterwards).
-    __shared__ __attribute__((aligned(16))) uint32_t s_tab[RS_WAVES * 256 + 512];
-    __shared__ uint32_t s_tmp[RS_WAVES + 1];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tab[WAVES * 256 + 512];
+    __shared__ uint32_t s_tmp[WAVES + 1];
     __shared__ uint8_t s_code[TEXT ? 256 : 4];
     // last pass of the suffix sort's initial sort: code -> byte for L.  From LDS: a table read from global memory made every one of a
     // thread's sixteen L stores wait for ALL its memory operations in flight, the key stores before it included (the memory counter
     // is in order): 0.65 ms for that pass of 1e8 pairs against 0.50 for the others.
     __shared__ uint8_t s_inv[256];
     if (fin.bwt && threadIdx.x < 256) s_inv[threadIdx.x] = fin.inv_code[threadIdx.x];  // (visible after the barriers below)
-    static_assert(!TEXT || sizeof(uint32_t) * (RS_WAVES * 256 + 512) >= RS_TILE + RS_TEXT_AHEAD + 16, "code staging does not fit");
+    static_assert(!TEXT || sizeof(uint32_t) * (WAVES * 256 + 512) >= RS_TILE + RS_TEXT_AHEAD + 16, "code staging does not fit");
     uint32_t (*s_cnt)[256] = reinterpret_cast<uint32_t (*)[256]>(s_tab);
-    uint32_t *s_start = s_tab + RS_WAVES * 256;
+    uint32_t *s_start = s_tab + WAVES * 256;
     uint32_t *s_gbase = s_start + 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t tile = blockIdx.x;
@@ -367,16 +373,16 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))
         text_tile_keys(tk, tile_base, s_code, reinterpret_cast<uint8_t *>(s_tab), [&](int o, uint64_t key) { s_keys[swz(static_cast<uint32_t>(o))] = key; });
         __syncthreads();
     } else {
-        for (int i = tid; i < RS_WAVES * 256; i += RS_BLOCK) s_tab[i] = 0;
+        for (int i = tid; i < WAVES * 256; i += BLOCK) s_tab[i] = 0;
         __syncthreads();
     }
 
     // wave w owns pairs [w*1024, (w+1)*1024) of the tile, lane-striped so that loads coalesce
-    uint64_t key[RS_KPT];
-    uint32_t val[RS_KPT];
-    const uint32_t wbase = static_cast<uint32_t>(wave) * (64 * RS_KPT);
+    uint64_t key[KPT];
+    uint32_t val[KPT];
+    const uint32_t wbase = static_cast<uint32_t>(wave) * (64 * KPT);
 #pragma unroll
-    for (int k = 0; k < RS_KPT; ++k) {
+    for (int k = 0; k < KPT; ++k) {
         const uint32_t li = wbase + k * 64 + lane;
         if (li < valid) {
             key[k] = TEXT ? s_keys[swz(li)] : load_key<PAIRS>(kin, vin, pair_lo, tile_base + li);  // PAIRS: vin holds the high words
@@ -388,14 +394,14 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))
     }
     if (TEXT) {  // the codes have been consumed: their place becomes the digit counters
         __syncthreads();
-        for (int i = tid; i < RS_WAVES * 256; i += RS_BLOCK) s_tab[i] = 0;
+        for (int i = tid; i < WAVES * 256; i += BLOCK) s_tab[i] = 0;
         __syncthreads();
     }
 
     // stable rank inside the wave: lanes holding the same digit find each other with 8 ballots
-    uint32_t rnk[RS_KPT];
+    uint32_t rnk[KPT];
 #pragma unroll
-    for (int k = 0; k < RS_KPT; ++k) {
+    for (int k = 0; k < KPT; ++k) {
         const uint32_t d = digit_of(key[k], shift);
         const LaneSet same = wave_match<8>(d, ~0ull);
         const uint32_t before = same.before();
@@ -413,14 +419,14 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))
         uint32_t run = 0, goff = 0;
         if (owner) {
 #pragma unroll
-            for (int w = 0; w < RS_WAVES; ++w) {
+            for (int w = 0; w < WAVES; ++w) {
                 const uint32_t c = s_cnt[w][d];
                 s_cnt[w][d] = run;
                 run += c;
             }
             goff = goff_early;
         }
-        const uint32_t start = block_excl_sum<RS_WAVES>(run, s_tmp, nullptr);
+        const uint32_t start = block_excl_sum<WAVES>(run, s_tmp, nullptr);
         if (owner) {
             s_start[d] = start;
             s_gbase[d] = goff - start;
@@ -428,19 +434,19 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))
     }
     __syncthreads();
 
-    uint32_t pos[RS_KPT];
+    uint32_t pos[KPT];
 #pragma unroll
-    for (int k = 0; k < RS_KPT; ++k) {
+    for (int k = 0; k < KPT; ++k) {
         const uint32_t d = digit_of(key[k], shift);
         pos[k] = s_start[d] + s_cnt[wave][d] + rnk[k];
         s_keys[pos[k]] = key[k];
     }
     __syncthreads();
 
-    uint32_t gi[RS_KPT];
+    uint32_t gi[KPT];
 #pragma unroll
-    for (int k = 0; k < RS_KPT; ++k) {
-        const uint32_t p = k * RS_BLOCK + tid;
+    for (int k = 0; k < KPT; ++k) {
+        const uint32_t p = k * BLOCK + tid;
         const uint64_t kk = s_keys[p];
         gi[k] = s_gbase[digit_of(kk, shift)] + p;
         if (p < valid) {
@@ -454,11 +460,11 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))
     __syncthreads();
     uint32_t *s_vals = reinterpret_cast<uint32_t *>(s_keys);
 #pragma unroll
-    for (int k = 0; k < RS_KPT; ++k) s_vals[pos[k]] = val[k];
+    for (int k = 0; k < KPT; ++k) s_vals[pos[k]] = val[k];
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < RS_KPT; ++k) {
-        const uint32_t p = k * RS_BLOCK + tid;
+    for (int k = 0; k < KPT; ++k) {
+        const uint32_t p = k * BLOCK + tid;
         if (p < valid) {
             const uint32_t v = s_vals[p];
             vout[gi[k]] = v;
@@ -629,6 +635,9 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
             if (tk)
                 k_radix_scatter<false, true><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(nullptr, nullptr, nullptr, keys_alt, vout, count, shift, offs,
                                                                                    xcd ? static_cast<uint32_t>(ntiles) : 0u, *tk, emit, fin);
+            else if (DK_KNOB("DK_SCATTER_BLOCK", DK_SCATTER_BLOCK_DEFAULT) == 512)
+                k_radix_scatter<false, false, 512><<<dim3(grid), dim3(512), 0, st>>>(keys, vals, nullptr, keys_alt, vout, count, shift, offs,
+                                                                                    xcd ? static_cast<uint32_t>(ntiles) : 0u, TextKeys{}, emit, fin);
             else
                 k_radix_scatter<false><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(keys, vals, nullptr, keys_alt, vout, count, shift, offs,
                                                                              xcd ? static_cast<uint32_t>(ntiles) : 0u, TextKeys{}, emit, fin);
