@@ -20,6 +20,9 @@ SPECS = {
     "wordlike_1e8": (lambda: datagen.word_like(100_000_000, 5), True),
     "realtext_5e7": (lambda: datagen.real_text(50_000_000, 0), True),  # real bytes: the image's own text files (no corpus is on disk)
 }
+# workloads whose suffix array is kept for a direct comparison: real text holds whole files twice, hundreds of thousands of neighbouring suffixes
+# with tens of kilobytes in common -- more than the pair-by-pair check of test_gpu_fullsize.py walks through
+KEEP_SA = {"realtext_5e7"}
 # small stand-ins with the same code path, for checking this module itself on the CPU (tests/test_oracle.py)
 SPECS_SMALL = {
     "small_text": (lambda: datagen.wiki_like(200_000, 2), True),
@@ -44,7 +47,12 @@ class _Job:
             t0 = time.perf_counter()
             block = make()
             t1 = time.perf_counter()
-            bwt, origin = orc.bwt_forward(block)                 # SA-IS + the TransformIterator convention
+            sa = None
+            if self.name in KEEP_SA:
+                sa = orc.sa_sais(block)
+                bwt, origin = orc.bwt_forward(block, sa)
+            else:
+                bwt, origin = orc.bwt_forward(block)             # SA-IS + the TransformIterator convention
             t2 = time.perf_counter()
             dc = orc.dc_encode(bwt)                              # init[256], d[m], sym[m], rank[m]
             dc.pop("sparse", None)
@@ -52,7 +60,7 @@ class _Job:
             t3 = time.perf_counter()
             stream = orc.block_dc_encode_bwt("dark", bwt, origin) if with_stream else None
             t4 = time.perf_counter()
-            self.result = dict(block=block, bwt=bwt, origin=origin, dc=dc, stream=stream,
+            self.result = dict(block=block, sa=sa, bwt=bwt, origin=origin, dc=dc, stream=stream,
                                seconds=dict(datagen=t1 - t0, sa_bwt=t2 - t1, dc=t3 - t2, stream=t4 - t3))
         except BaseException as e:  # noqa: BLE001 -- re-raised by get()
             self.error = e
