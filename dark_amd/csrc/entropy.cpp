@@ -1158,39 +1158,54 @@ __attribute__((noinline)) int code_uniform(URing &ring, uint8_t *out, size_t cap
             //     span -> r (mulx) -> low + r * from (imul, add) -> xor with the upper border -> clz & 24 -> shifted span.
             uint8_t *p = out + len;
             uint32_t low = rs.low, span = rs.hi - rs.low;
+            // The quotient of the NEXT decision is asked for before this one's byte shift is known: five decisions in six shift nothing out and
+            // nearly all the others one byte, so r' = (s * inv') >> 64 and ((s << 8) * inv') >> 64 are both started as soon as the new span s is
+            // there, and the count of leading zeros only picks one of them.  The chain from one decision to the next is then
+            //     r -> s = r * width (imul) -> r' (mulx) -> select,
+            // eight cycles where the straight form (mulx -> imul, add -> xor -> clz & 24 -> shift -> mulx) has twelve; a shift of two or three
+            // bytes, or a threshold cut, computes its quotient again (rare, predicted).
+            uint32_t r = count ? static_cast<uint32_t>((static_cast<unsigned __int128>(span) * ev[0].inv) >> 64) : 0u;
             for (uint32_t k = 0; k < count; ++k) {
-                const uint32_t r = static_cast<uint32_t>((static_cast<unsigned __int128>(span) * ev[k].inv) >> 64);
+                const uint64_t inv_next = ev[k + 1 < count ? k + 1 : k].inv;  // (the last decision of a batch: its own again, never used)
                 uint32_t lo = low + r * ev[k].from, h = low + r * ev[k].to, s = r * (ev[k].to - ev[k].from);
+                const uint32_t r_stay = static_cast<uint32_t>((static_cast<unsigned __int128>(s) * inv_next) >> 64);
+                uint32_t r_byte = static_cast<uint32_t>((static_cast<unsigned __int128>(static_cast<uint64_t>(s) << 8) * inv_next) >> 64);
+                // (both products, then the choice: left alone the compiler chooses between s and s << 8 first and multiplies once -- the shift
+                // count back on the chain in front of the multiply)
+                uint32_t r_stay_ = r_stay;
+                __asm__("" : "+r"(r_stay_), "+r"(r_byte));
                 const uint32_t x = lo ^ h;
                 if (__builtin_expect(r == 0 || x == 0, 0)) { err = DK_E_INTERNAL; break; }
-                // (branch-free on purpose.  Five events in six leave no byte, and a branch would take the shift off the span's dependent
-                // chain when predicted: measured in round 4, 423.7 against 393.9 ms per 1e8-byte block -- the predictor does not see it coming.)
                 const unsigned sh = static_cast<unsigned>(__builtin_clz(x)) & 24u;
                 const uint32_t be = __builtin_bswap32(lo);
                 std::memcpy(p, &be, 4);
                 p += sh >> 3;
                 lo <<= sh;
                 s <<= sh;
-                if (__builtin_expect(s <= kRangeThreshold, 0)) {  // threshold cut: the reference's loop from its second round on
-                    h = lo + s;
-                    int shifted = static_cast<int>(sh >> 3);
-                    for (;;) {
-                        const uint32_t lim = h & kTopMask;
-                        if (h - lim >= lim - lo) lo = lim; else h = lim - 1;
-                        const uint32_t x2 = lo ^ h;
-                        if (x2 == 0) { err = DK_E_INTERNAL; break; }
-                        const unsigned sh2 = static_cast<unsigned>(__builtin_clz(x2)) & 24u;
-                        const uint32_t be2 = __builtin_bswap32(lo);
-                        std::memcpy(p, &be2, 4);
-                        p += sh2 >> 3;
-                        shifted += static_cast<int>(sh2 >> 3);
-                        if (shifted > 4) { err = DK_E_INTERNAL; break; }
-                        lo <<= sh2;
-                        h <<= sh2;
-                        if (h - lo > kRangeThreshold) break;
+                r = sh ? r_byte : r_stay_;
+                if (__builtin_expect(sh > 8u || s <= kRangeThreshold, 0)) {
+                    if (s <= kRangeThreshold) {  // threshold cut: the reference's loop from its second round on
+                        h = lo + s;
+                        int shifted = static_cast<int>(sh >> 3);
+                        for (;;) {
+                            const uint32_t lim = h & kTopMask;
+                            if (h - lim >= lim - lo) lo = lim; else h = lim - 1;
+                            const uint32_t x2 = lo ^ h;
+                            if (x2 == 0) { err = DK_E_INTERNAL; break; }
+                            const unsigned sh2 = static_cast<unsigned>(__builtin_clz(x2)) & 24u;
+                            const uint32_t be2 = __builtin_bswap32(lo);
+                            std::memcpy(p, &be2, 4);
+                            p += sh2 >> 3;
+                            shifted += static_cast<int>(sh2 >> 3);
+                            if (shifted > 4) { err = DK_E_INTERNAL; break; }
+                            lo <<= sh2;
+                            h <<= sh2;
+                            if (h - lo > kRangeThreshold) break;
+                        }
+                        if (err) break;
+                        s = h - lo;
                     }
-                    if (err) break;
-                    s = h - lo;
+                    r = static_cast<uint32_t>((static_cast<unsigned __int128>(s) * inv_next) >> 64);
                 }
                 low = lo;
                 span = s;
