@@ -1,4 +1,4 @@
-// host entropy stage alone on the sample written by tools/make_dc_sample.py: six encodes (DK_ENTROPY_THREADS selects the form), one decode
+// host entropy stage alone on the sample written by tools/make_dc_sample.py: six encodes (DK_ENTROPY_THREADS selects the form), five decodes
 #include "../dark_amd/csrc/entropy.hpp"
 #include <chrono>
 #include <cstdio>
@@ -18,8 +18,10 @@ int main(int argc,char**argv){
     printf("rc=%d len=%zu  %.1f ms  %.1f ns/dist  %.1f MB/s\n",rc,len,ms,ms*1e6/m,n/ms/1e3);
   }
   std::vector<uint8_t> bwt(n); uint32_t o2; int single;
+  for(int it=0;it<5;it++){
   auto t0=std::chrono::steady_clock::now();
   int rc=decode_block_stream(0,out.data(),len,n,bwt.data(),&o2,&single);
   double ms=std::chrono::duration<double,std::milli>(std::chrono::steady_clock::now()-t0).count();
   printf("decode rc=%d %.1f ms %.1f ns/dist\n",rc,ms,ms*1e6/m);
+  }
 }
