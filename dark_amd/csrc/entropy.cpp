@@ -363,6 +363,11 @@ __attribute__((noinline)) int wait_for_entries(const DcStream &s, size_t k, size
     return DK_OK;
 }
 
+template <class M, class E, class = void> struct has_bulk : std::false_type {};
+template <class M, class E>
+struct has_bulk<M, E, decltype(void(std::declval<M &>().bulk(static_cast<const uint32_t *>(nullptr), static_cast<const uint8_t *>(nullptr), size_t(0), std::declval<E &>())))>
+    : std::true_type {};
+
 // src/block/dc.rs:54-90 with any model M
 template <class M, class E>
 int write_stream(M &model, const DcStream &s, E &e) {
@@ -397,8 +402,13 @@ int write_stream(M &model, const DcStream &s, E &e) {
             const int rc = wait_for_entries(s, k, &have);
             if (rc != DK_OK) return rc;
         }
-        for (; k < have; ++k)
-            if (!code(s.dist[k], s.sym[k])) return fail();
+        if constexpr (has_bulk<M, E>::value) {  // a stage that walks a whole stretch with its cursors in registers (the four-stage pipeline's merger)
+            if (!model.bulk(s.dist + k, s.sym + k, have - k, e)) return fail();
+            k = have;
+        } else {
+            for (; k < have; ++k)
+                if (!code(s.dist[k], s.sym[k])) return fail();
+        }
     }
     if (!code(s.origin, 0)) return fail();  // src/block/dc.rs:88 under CTX_0
     if (!e.finish()) return e.error();
@@ -1015,6 +1025,9 @@ public:
         return cur_ + fill_;
     }
     inline void advance(uint32_t count) { fill_ += count; }
+    // cursor interface (merger's bulk loop): the free places of the current batch as a pointer range; done(p) = everything before p is written
+    inline UEvent *cursor(UEvent **end) { *end = cur_ + URing::kBatch; return cur_ + fill_; }
+    inline void done(UEvent *p) { fill_ = static_cast<uint32_t>(p - cur_); }
     inline bool put(uint32_t total, uint32_t from, uint32_t to) {
         if (!(from < to && to <= total && total < 32768u && total >= 2u)) return fail(DK_E_INTERNAL);
         return raw(UEvent{total < (1u << 14) ? inv_[total] : reciprocal64(total), from, to});
@@ -1058,6 +1071,8 @@ public:
     inline const UEvent *head() const { return cur_ + pos_; }
     inline void skip(uint32_t count) { pos_ += count; }
     inline bool refill_batch() { return refill(); }
+    inline const UEvent *cursor(const UEvent **end) const { *end = cur_ + count_; return cur_ + pos_; }
+    inline void done(const UEvent *p) { pos_ = static_cast<uint32_t>(p - cur_); }
     void drain() {
         while (!last_) { ring_.release(slot_); slot_ = (slot_ + 1) % URing::kSlots; next_batch(); }
         ring_.release(slot_);
@@ -1143,6 +1158,48 @@ struct DarkMergeSide {  // the order of dark.rs:180-232: table decision, unary e
         const unsigned log = bit_length(dist + 1);
         if (!move(exponent, e, 1 + DarkModel::exponent_bits(dist)) || !move(mantissa, e, DarkModel::modelled_mantissa_bits(dist))) return false;
         if (log > 4) flat_tail(e, dist + 1, log);
+        return true;
+    }
+    // A stretch of distances with the three rings' cursors in registers.  Through encode() every copy goes through the sink's and the readers'
+    // members, which the compiler reloads after each 64-byte copy (the copy might have written them, for all it knows): three store-to-load
+    // round trips in a row on the sink's fill count alone, per distance -- the merger had become the pipeline's slowest stage.  The common
+    // distance (at most four exponent decisions, at most four flat bits, four events left in both input batches, twelve places in the output
+    // batch) is copied here with plain pointers; anything else takes encode() between two synchronisations of the cursors.
+    bool bulk(const uint32_t *dist, const uint8_t *, size_t count, USink &e) {
+        const UEvent *pe_end, *pm_end, *pe = exponent.cursor(&pe_end), *pm = mantissa.cursor(&pm_end);
+        UEvent *o_end, *o = e.cursor(&o_end);
+        for (size_t k = 0; k < count; ++k) {
+            const uint32_t d = dist[k];
+            const unsigned log = bit_length(d + 1);  // (d = 2^32 - 1 gives 0 and goes the slow way, which refuses it)
+            const unsigned ne = 1 + (log >= 8 ? log - 7 : 0), nm = log > 3 ? 3 : log - 1;
+            if (__builtin_expect(log - 1u <= 7u && pe + 4 <= pe_end && pm + 4 <= pm_end && o + 12 <= o_end, 1)) {  // log 1 .. 8: ne <= 2, flat bits <= 4
+                std::memcpy(static_cast<void *>(o), pe, 4 * sizeof(UEvent));
+                o += ne;
+                pe += ne;
+                std::memcpy(static_cast<void *>(o), pm, 4 * sizeof(UEvent));
+                o += nm;
+                pm += nm;
+                const uint32_t v = d + 1;
+                const unsigned left = log > 4 ? log - 4 : 0;  // flat bits left - 1 .. 0 of v, most significant first
+#pragma GCC unroll 4
+                for (unsigned j = 0; j < 4; ++j) {
+                    const uint32_t one = (v >> ((left - 1 - j) & 31u)) & 1u;
+                    o[j] = UEvent{1ull << 52, one << 11, 2048u + (one << 11)};
+                }
+                o += left;
+                continue;
+            }
+            exponent.done(pe);
+            mantissa.done(pm);
+            e.done(o);
+            if (!encode(d, 0, e)) return false;
+            pe = exponent.cursor(&pe_end);
+            pm = mantissa.cursor(&pm_end);
+            o = e.cursor(&o_end);
+        }
+        exponent.done(pe);
+        mantissa.done(pm);
+        e.done(o);
         return true;
     }
 };
