@@ -204,7 +204,7 @@ def stub_exchange(args, world, rank):
     d, sym = rank_input(rank)
     # the same planning of the host coding threads as the real run: the smallest number of claimable L3 groups over the ranks decides for all
     from dark_amd import entropy as dk_entropy
-    groups = [dk_entropy.l3_groups(4), dk_entropy.l3_groups(2)]
+    groups = [dk_entropy.l3_groups(4), dk_entropy.l3_groups(2), dk_entropy.l3_groups(5)]
     gt = torch.tensor(groups, dtype=torch.int64)
     if world > 1:
         dist.all_reduce(gt, op=dist.ReduceOp.MIN)
@@ -212,7 +212,7 @@ def stub_exchange(args, world, rank):
     if "DK_ENTROPY_THREADS" in os.environ:
         thread_plan = int(os.environ["DK_ENTROPY_THREADS"])
     else:
-        thread_plan = dk_entropy.plan_threads(int(gt[0]), int(gt[1]), world, share)
+        thread_plan = dk_entropy.plan_threads(int(gt[0]), int(gt[1]), world, share, int(gt[2]))
         dk_entropy.set_threads(thread_plan)
 
     def step():
@@ -267,12 +267,13 @@ def rank_report(rank, steps, elapsed, stage_acc, threads_seen, groups_seen, grou
             "host_entropy_threads": min(threads_seen) if threads_seen else None,
             "host_entropy_threads_max": max(threads_seen) if threads_seen else None,
             "l3_group": groups_seen[-1] if groups_seen else None,
-            "l3_groups_with_4_cores": int(groups_visible[0]), "l3_groups_with_2_cores": int(groups_visible[1])}
+            "l3_groups_with_4_cores": int(groups_visible[0]), "l3_groups_with_2_cores": int(groups_visible[1]),
+            "l3_groups_with_5_cores": int(groups_visible[2]) if len(groups_visible) > 2 else 0}
 
 
 def thread_summary(reports, plan):
     """-> keys for the JSON line: the plan, every rank's report, and which ranks coded on fewer threads than planned"""
-    want = plan if plan in (1, 2, 4) else None
+    want = plan if plan in (1, 2, 4, 5) else None
     short = [r["rank"] for r in reports if want and r["host_entropy_threads"] is not None and r["host_entropy_threads"] < want]
     return {"entropy_thread_plan": plan, "ranks": reports, "entropy_fallback_ranks": short,
             "entropy_fallback": ("ranks %s coded on fewer host threads than planned (%d): max-over-ranks is theirs" % (short, want)) if short else None}
@@ -329,7 +330,7 @@ def main():
     # One coding pipeline per rank needs one last-level-cache group per rank.  Every rank reports how many groups it could claim; the
     # smallest answer decides the thread form of ALL ranks, so that max-over-ranks is not decided by who loses the race for a group.
     from dark_amd import entropy as dk_entropy
-    groups = [dk_entropy.l3_groups(4), dk_entropy.l3_groups(2)]
+    groups = [dk_entropy.l3_groups(4), dk_entropy.l3_groups(2), dk_entropy.l3_groups(5)]
     if use_dist:
         gt = torch.tensor(groups, dtype=torch.int64)
         dist.all_reduce(gt, op=dist.ReduceOp.MIN, group=host_group)
@@ -339,7 +340,7 @@ def main():
     if "DK_ENTROPY_THREADS" in os.environ:
         thread_plan = int(os.environ["DK_ENTROPY_THREADS"])
     else:
-        thread_plan = dk_entropy.plan_threads(groups_min[0], groups_min[1], world, share)
+        thread_plan = dk_entropy.plan_threads(groups_min[0], groups_min[1], world, share, groups_min[2])
         dk_entropy.set_threads(thread_plan)
 
     t_gen = time.time()

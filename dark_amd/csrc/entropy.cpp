@@ -83,6 +83,46 @@ bool DarkModel::encode_exponent(uint32_t dist, uint8_t symbol, E &e) {  // dark.
 static_assert(kMaxLogCode == 8, "DarkModel::exponent_bits assumes MAX_LOG_CODE = 8");
 
 template <class E>
+bool DarkModel::encode_exponent_symbol_half(uint32_t dist, uint8_t symbol, E &e) {  // the per-symbol state of encode_exponent(): log_freq, extra, avg_dist
+    if (dist >= 0x7FFFFFFFu) return false;
+    const unsigned log = bit_length(dist + 1);
+    PerSymbol &c = sym_[symbol];
+    const unsigned avg_log = std::min(kMaxLogContext, bit_length(static_cast<uint32_t>(c.avg_dist)));
+    const size_t code = std::min(log, kMaxLogCode) - 1;
+    e.half(c.log_freq.total, c.log_freq.below(code), c.log_freq.f[code]);
+    c.log_freq.bump(code, kLogSymbolRate, kLogAdd);
+    if (log >= kMaxLogCode) {
+        for (unsigned i = 0; i + kMaxLogCode <= log; ++i) {  // log - 7 decisions: ones, then a zero
+            e.half_bit(c.extra[i].zero);
+            c.extra[i].learn<3>(i + kMaxLogCode < log);
+        }
+    }
+    adapt(c, dist, static_cast<int>(log) - static_cast<int>(avg_log));
+    return true;
+}
+template <class E>
+bool DarkModel::encode_exponent_global_half(uint32_t dist, uint8_t symbol, E &e) {  // the shared state: log_global_, log_bits_, last_token_ (+ its own avg_dist)
+    if (dist >= 0x7FFFFFFFu) return false;
+    const unsigned log = bit_length(dist + 1);
+    PerSymbol &c = sym_[symbol];  // (only avg_dist of it is used here)
+    const unsigned avg_log = std::min(kMaxLogContext, bit_length(static_cast<uint32_t>(c.avg_dist)));
+    FreqTable<8> &g = log_global_[avg_log][last_token_];
+    const size_t code = std::min(log, kMaxLogCode) - 1;
+    e.half(g.total, g.below(code), g.f[code]);
+    g.bump(code, kLogGlobalRate, kLogAdd);
+    if (log >= kMaxLogCode) {
+        BinFreq *gb = log_bits_[avg_log == kMaxLogContext ? 1 : 0];
+        for (unsigned i = 0; i + kMaxLogCode <= log; ++i) {
+            e.half_bit(gb[i].zero);
+            gb[i].learn<2>(i + kMaxLogCode < log);
+        }
+    }
+    last_token_ = token_of(log);
+    adapt(c, dist, static_cast<int>(log) - static_cast<int>(avg_log));
+    return true;
+}
+
+template <class E>
 bool DarkModel::encode_mantissa_modelled(uint32_t dist, E &e) {  // dark.rs:216-224: the first three bits below the leading one
     if (dist >= 0x7FFFFFFFu) return false;
     const uint32_t v = dist + 1;
@@ -1034,6 +1074,9 @@ public:
     }
     inline bool put_pow2(unsigned shift, uint32_t from, uint32_t to) { return raw(UEvent{1ull << (64 - shift), from, to}); }
     inline bool put_bit12(uint32_t zero, bool one) { return raw(UEvent{1ull << 52, one ? zero : 0u, one ? 4096u : zero}); }
+    // half of a mixed decision (five-stage pipeline): from = what lies below the symbol, to = frequency << 16 | total; half of a mixed bit: from = zero
+    inline bool half(uint32_t total, uint32_t below, uint32_t freq) { return raw(UEvent{0, below, (freq << 16) | total}); }
+    inline bool half_bit(uint32_t zero) { return raw(UEvent{0, zero, 0}); }
     bool finish() {
         if (!cur_) return err_ == 0;
         ring_.publish(slot_, fill_ | URing::kEnd);
@@ -1109,9 +1152,32 @@ struct DarkExponentSide {
 // (only the three MODELLED mantissa bits: the flat tail below them goes through a model that never learns, dark.rs:225-227 -- no state, so
 // the merger makes those events itself.  With the tail on this thread it was the pipeline's slowest stage: it never waited, the other
 // three did; profiles/r04_entropy_ab.json)
+// a sink that is nothing but a pointer into the current batch: a local of the caller, so it lives in a register (USink's fill count is a
+// member the compiler reloads after every 16-byte store it cannot tell apart from it: one store-to-load round trip per decision)
+struct UCursor {
+    UEvent *o;
+    inline bool put_bit12(uint32_t zero, bool one) { *o++ = UEvent{1ull << 52, one ? zero : 0u, one ? 4096u : zero}; return true; }
+    inline bool half(uint32_t total, uint32_t below, uint32_t freq) { *o++ = UEvent{0, below, (freq << 16) | total}; return true; }
+    inline bool half_bit(uint32_t zero) { *o++ = UEvent{0, zero, 0}; return true; }
+};
 struct DarkMantissaSide {
     DarkModel &m;
     bool encode(uint32_t dist, uint8_t, USink &e) { return m.encode_mantissa_modelled(dist, e); }
+    bool bulk(const uint32_t *dist, const uint8_t *, size_t count, USink &e) {  // at most three decisions per distance
+        UEvent *o_end;
+        UCursor c{e.cursor(&o_end)};
+        for (size_t k = 0; k < count; ++k) {
+            if (__builtin_expect(c.o + 3 <= o_end, 1)) {
+                if (!m.encode_mantissa_modelled(dist[k], c)) { e.done(c.o); return false; }
+            } else {
+                e.done(c.o);
+                if (!m.encode_mantissa_modelled(dist[k], e)) return false;
+                c.o = e.cursor(&o_end);
+            }
+        }
+        e.done(c.o);
+        return true;
+    }
 };
 struct DarkMergeSide {  // the order of dark.rs:180-232: table decision, unary extension, mantissa bits
     UReader &exponent;
@@ -1198,6 +1264,118 @@ struct DarkMergeSide {  // the order of dark.rs:180-232: table decision, unary e
             o = e.cursor(&o_end);
         }
         exponent.done(pe);
+        mantissa.done(pm);
+        e.done(o);
+        return true;
+    }
+};
+
+// Five stages: the exponent model itself in two halves (DarkModel::encode_exponent_symbol_half / _global_half), added up by the merger --
+//     per-symbol tables -> ring A \
+//     global tables     -> ring B  >  merger  ->  ring U  ->  range coder
+//     mantissa model    -> ring M /
+// With the coder's chain shortened and the merger's cursors in registers the exponent model was the slowest stage (it never waited, the
+// other three did): its table decision is a + 2 b of a per-symbol and a global table, its extra bits the mean of a per-symbol and a global
+// probability, and neither side reads the other's state.
+struct DarkSymbolHalfSide {
+    DarkModel &m;
+    bool encode(uint32_t dist, uint8_t symbol, USink &e) { return m.encode_exponent_symbol_half(dist, symbol, e); }
+    bool bulk(const uint32_t *dist, const uint8_t *sym, size_t count, USink &e) {  // at most 1 + 25 half decisions per distance
+        UEvent *o_end;
+        UCursor c{e.cursor(&o_end)};
+        for (size_t k = 0; k < count; ++k) {
+            if (__builtin_expect(c.o + 32 <= o_end, 1)) {
+                if (!m.encode_exponent_symbol_half(dist[k], sym[k], c)) { e.done(c.o); return false; }
+            } else {
+                e.done(c.o);
+                if (!m.encode_exponent_symbol_half(dist[k], sym[k], e)) return false;
+                c.o = e.cursor(&o_end);
+            }
+        }
+        e.done(c.o);
+        return true;
+    }
+};
+struct DarkGlobalHalfSide {
+    DarkModel &m;
+    bool encode(uint32_t dist, uint8_t symbol, USink &e) { return m.encode_exponent_global_half(dist, symbol, e); }
+    bool bulk(const uint32_t *dist, const uint8_t *sym, size_t count, USink &e) {
+        UEvent *o_end;
+        UCursor c{e.cursor(&o_end)};
+        for (size_t k = 0; k < count; ++k) {
+            if (__builtin_expect(c.o + 32 <= o_end, 1)) {
+                if (!m.encode_exponent_global_half(dist[k], sym[k], c)) { e.done(c.o); return false; }
+            } else {
+                e.done(c.o);
+                if (!m.encode_exponent_global_half(dist[k], sym[k], e)) return false;
+                c.o = e.cursor(&o_end);
+            }
+        }
+        e.done(c.o);
+        return true;
+    }
+};
+struct DarkMergeSide5 {
+    UReader &half_a, &half_b, &mantissa;
+    const uint64_t *inv;
+    static inline UEvent mixed(const UEvent &a, const UEvent &b, const uint64_t *inv) {  // table::SumProxy::new(1, a, 2, b, 0) of the two halves
+        const uint32_t total = (a.to & 0xFFFFu) + 2u * (b.to & 0xFFFFu), from = a.from + 2u * b.from, freq = (a.to >> 16) + 2u * (b.to >> 16);
+        return UEvent{inv[total & 0x3FFFu], from, from + freq};  // (totals stay below 3 * 2^12)
+    }
+    static inline UEvent mixed_bit(const UEvent &a, const UEvent &b, bool one) {
+        const uint32_t zero = (a.from + b.from) >> 1;
+        return UEvent{1ull << 52, one ? zero : 0u, one ? 4096u : zero};
+    }
+    bool encode(uint32_t dist, uint8_t, USink &e) {
+        if (dist >= 0x7FFFFFFFu) return false;
+        const unsigned log = bit_length(dist + 1);
+        const UEvent *a = half_a.next(), *b = half_b.next();
+        if (!a || !b) return false;
+        e.raw(mixed(*a, *b, inv));
+        for (unsigned i = 0; i + kMaxLogCode <= log; ++i) {
+            a = half_a.next();
+            b = half_b.next();
+            if (!a || !b) return false;
+            e.raw(mixed_bit(*a, *b, i + kMaxLogCode < log));
+        }
+        if (!DarkMergeSide::move(mantissa, e, DarkModel::modelled_mantissa_bits(dist))) return false;
+        if (log > 4) DarkMergeSide::flat_tail(e, dist + 1, log);
+        return true;
+    }
+    bool bulk(const uint32_t *dist, const uint8_t *, size_t count, USink &e) {  // (see DarkMergeSide::bulk)
+        const UEvent *pa_end, *pb_end, *pm_end, *pa = half_a.cursor(&pa_end), *pb = half_b.cursor(&pb_end), *pm = mantissa.cursor(&pm_end);
+        UEvent *o_end, *o = e.cursor(&o_end);
+        for (size_t k = 0; k < count; ++k) {
+            const uint32_t d = dist[k];
+            const unsigned log = bit_length(d + 1);
+            const unsigned nm = log > 3 ? 3 : log - 1;
+            if (__builtin_expect(log - 1u <= 6u && pa < pa_end && pb < pb_end && pm + 4 <= pm_end && o + 12 <= o_end, 1)) {  // log 1 .. 7: one mixed decision, flat bits <= 3
+                *o++ = mixed(*pa++, *pb++, inv);
+                std::memcpy(static_cast<void *>(o), pm, 4 * sizeof(UEvent));
+                o += nm;
+                pm += nm;
+                const uint32_t v = d + 1;
+                const unsigned left = log > 4 ? log - 4 : 0;
+#pragma GCC unroll 4
+                for (unsigned j = 0; j < 4; ++j) {
+                    const uint32_t one = (v >> ((left - 1 - j) & 31u)) & 1u;
+                    o[j] = UEvent{1ull << 52, one << 11, 2048u + (one << 11)};
+                }
+                o += left;
+                continue;
+            }
+            half_a.done(pa);
+            half_b.done(pb);
+            mantissa.done(pm);
+            e.done(o);
+            if (!encode(d, 0, e)) return false;
+            pa = half_a.cursor(&pa_end);
+            pb = half_b.cursor(&pb_end);
+            pm = mantissa.cursor(&pm_end);
+            o = e.cursor(&o_end);
+        }
+        half_a.done(pa);
+        half_b.done(pb);
         mantissa.done(pm);
         e.done(o);
         return true;
@@ -1298,6 +1476,60 @@ __attribute__((noinline)) int code_uniform(URing &ring, uint8_t *out, size_t cap
     return err;
 }
 
+// Five stages where the L3 group has five cores for it.  DK_E_NODEVICE: no such group (or a helper thread could not be started).
+int encode_five_stages(DarkModel &model, const DcStream &s, uint8_t *out, size_t cap, size_t *out_len) {
+    ThreadPair tp;
+    if (!tp.acquire(5)) return DK_E_NODEVICE;
+    const uint64_t *inv = reciprocal_table();
+    URing ring_a, ring_b, ring_m, ring_u;
+    int rc_a = DK_OK, rc_b = DK_OK, rc_m = DK_OK, rc_u = DK_OK;
+    auto global_model = std::make_unique<DarkModel>(), mantissa_model = std::make_unique<DarkModel>();  // (own objects: no cache line shared between the threads' states)
+    std::thread t_a, t_b, t_m, t_u;
+    auto run_a = [&] { tp.pin_partner(); USink sink(ring_a); DarkSymbolHalfSide side{model}; rc_a = write_stream(side, s, sink); sink.finish(); };
+    auto run_b = [&] { tp.pin_partner(); USink sink(ring_b); DarkGlobalHalfSide side{*global_model}; rc_b = write_stream(side, s, sink); sink.finish(); };
+    auto run_m = [&] { tp.pin_partner(); USink sink(ring_m); DarkMantissaSide side{*mantissa_model}; rc_m = write_stream(side, s, sink); sink.finish(); };
+    auto run_u = [&] {
+        tp.pin_partner();
+        UReader rd_a(ring_a), rd_b(ring_b), rd_m(ring_m);
+        USink sink(ring_u);
+        DarkMergeSide5 side{rd_a, rd_b, rd_m, inv};
+        rc_u = write_stream(side, s, sink);
+        sink.finish();
+        rd_a.drain();
+        rd_b.drain();
+        rd_m.drain();
+    };
+    int started = 0;
+    try {
+        t_a = std::thread(run_a); ++started;
+        t_b = std::thread(run_b); ++started;
+        t_m = std::thread(run_m); ++started;
+        t_u = std::thread(run_u); ++started;
+    } catch (...) {
+        // let whatever did start run to its end: somebody has to empty the rings it fills
+        if (started >= 1) { UReader rd(ring_a); rd.drain(); t_a.join(); }
+        if (started >= 2) { UReader rd(ring_b); rd.drain(); t_b.join(); }
+        if (started >= 3) { UReader rd(ring_m); rd.drain(); t_m.join(); }
+        tp.release();
+        return DK_E_NODEVICE;
+    }
+    const int rc = code_uniform(ring_u, out, cap, out_len);
+    t_u.join();
+    t_a.join();
+    t_b.join();
+    t_m.join();
+    tp.release();
+    if (getenv("DK_TRACE"))
+        fprintf(stderr, "[dark_amd] entropy: five stages inside the L3 group of cpu %d; waits (pause iterations): symbol half %llu, global half %llu, "
+                        "mantissa model %llu, merger in %llu + %llu + %llu out %llu, coder %llu\n", tp.me, (unsigned long long)ring_a.producer_spins,
+                (unsigned long long)ring_b.producer_spins, (unsigned long long)ring_m.producer_spins, (unsigned long long)ring_a.consumer_spins,
+                (unsigned long long)ring_b.consumer_spins, (unsigned long long)ring_m.consumer_spins, (unsigned long long)ring_u.producer_spins,
+                (unsigned long long)ring_u.consumer_spins);
+    return rc_a ? rc_a : (rc_b ? rc_b : (rc_m ? rc_m : (rc_u ? rc_u : rc)));
+}
+template <class M>
+int encode_five_stages(M &, const DcStream &, uint8_t *, size_t, size_t *) { return DK_E_NODEVICE; }
+
 // DK_E_NODEVICE: fewer than four cores in the caller's L3 group (or a helper thread could not be started)
 int encode_four_stages(DarkModel &model, const DcStream &s, uint8_t *out, size_t cap, size_t *out_len) {
     ThreadPair tp;
@@ -1381,7 +1613,8 @@ int cgroup_cpu_budget() {
     return budget;
 }
 
-// 0 = automatic, 1 = one thread, 2 = models | coder, 4 = the four-stage pipeline (dark model), each whenever the cores exist.
+// 0 = automatic, 1 = one thread, 2 = models | coder, 4 = the four-stage pipeline (dark model), 5 = five stages (the exponent model in two
+// halves), each whenever the cores exist (else the next narrower form).
 // Process-wide: DK_ENTROPY_THREADS at load time, dk_set_entropy_threads() afterwards (a launcher that has compared what every rank of a
 // node can claim sets the same form on all of them, so that the slowest rank is not decided by who wins the race for an L3 group).
 std::atomic<int> g_thread_mode{[] { const char *e = getenv("DK_ENTROPY_THREADS"); return e ? atoi(e) : 0; }()};
@@ -1395,7 +1628,7 @@ int last_entropy_threads() { return t_last_threads; }
 namespace { void note_group(int id) { t_last_group = id; } }
 int last_entropy_group() { return t_last_threads > 1 ? t_last_group : -1; }
 int set_entropy_thread_mode(int mode) {
-    if (mode != 0 && mode != 1 && mode != 2 && mode != 4) return DK_E_ARG;
+    if (mode != 0 && mode != 1 && mode != 2 && mode != 4 && mode != 5) return DK_E_ARG;
     g_thread_mode.store(mode, std::memory_order_relaxed);
     return DK_OK;
 }
@@ -1434,12 +1667,17 @@ int encode_block_stream(int model_id, const DcStream &s, uint8_t *out, size_t ca
         t_last_group = -1;
         const bool large = s.m >= (1u << 21);
         const int budget = cgroup_cpu_budget();
-        if (mode == 4 || (mode == 0 && large && budget >= 4)) {
+        if (mode == 5 || (mode == 0 && large && budget >= 5)) {
+            const int rc5 = encode_five_stages(model, s, out, cap, out_len);
+            if (rc5 != DK_E_NODEVICE) { t_last_threads = 5; return rc5; }
+            model.reset();  // not this model, or fewer than five cores: try four stages
+        }
+        if (mode == 4 || mode == 5 || (mode == 0 && large && budget >= 4)) {
             const int rc4 = encode_four_stages(model, s, out, cap, out_len);
             if (rc4 != DK_E_NODEVICE) { t_last_threads = 4; return rc4; }
             model.reset();  // not this model, or fewer than four cores: try two threads
         }
-        if (mode == 2 || mode == 4 || (mode == 0 && large && budget >= 2)) {
+        if (mode == 2 || mode == 4 || mode == 5 || (mode == 0 && large && budget >= 2)) {
             const int rc2 = encode_two_threads(model, s, out, cap, out_len);
             if (rc2 != DK_E_NODEVICE) { t_last_threads = 2; return rc2; }
             model.reset();  // no partner core: fall through to the single-thread coder

@@ -409,6 +409,12 @@ public:
     // thread that knows the distance can produce those decisions by itself (two-thread encode, entropy.cpp).
     template <class E> bool encode_exponent(uint32_t dist, uint8_t symbol, E &e);
     template <class E> bool encode_mantissa_modelled(uint32_t dist, E &e);
+    // encode_exponent() in two halves that share no state (five-stage pipeline, entropy.cpp): the table decision mixes a per-symbol table a
+    // and a global table b as a + 2 b, which is linear -- one thread can emit (total, below, frequency) of a, another of b, and whoever adds
+    // them up gets the decision encode_exponent() would have coded.  Both halves follow avg_dist of every symbol by themselves (adapt()).
+    // E::half(total, below, freq) / E::half_bit(zero) take what the halves produce.
+    template <class E> bool encode_exponent_symbol_half(uint32_t dist, uint8_t symbol, E &e);
+    template <class E> bool encode_exponent_global_half(uint32_t dist, uint8_t symbol, E &e);
     template <class E> static bool encode_mantissa_flat(uint32_t dist, E &e);  // stateless
     // number of binary decisions encode_exponent emits after its one table decision
     static unsigned exponent_bits(uint32_t dist) { const unsigned log = bit_length(dist + 1); return log >= 8 ? log - 7 : 0; }

@@ -33,7 +33,7 @@ def decode_bits(stream, flat):
 
 # ---- host coding threads (include/dark_amd.h "host coding threads") ----------------------------------------------------------------
 def set_threads(mode):
-    """thread form of the host coding pass, process-wide: 0 automatic | 1 | 2 | 4"""
+    """thread form of the host coding pass, process-wide: 0 automatic | 1 | 2 | 4 | 5"""
     rc = _lib.load().dk_set_entropy_threads(int(mode))
     if rc:
         raise DarkError(rc, "dk_set_entropy_threads(%r)" % (mode,))
@@ -51,9 +51,11 @@ def last_info():
     return int(t.value), int(g.value)
 
 
-def plan_threads(groups4, groups2, ranks, share):
-    """The thread form every rank of a node should use so that none of them loses the race for an L3 group: groups4 / groups2 = the
-    SMALLEST number of groups with >= 4 / >= 2 usable cores any rank sees, ranks = ranks on the node, share = host CPUs per rank."""
+def plan_threads(groups4, groups2, ranks, share, groups5=0):
+    """The thread form every rank of a node should use so that none of them loses the race for an L3 group: groups5 / groups4 / groups2 = the
+    SMALLEST number of groups with >= 5 / >= 4 / >= 2 usable cores any rank sees, ranks = ranks on the node, share = host CPUs per rank."""
+    if share >= 5 and groups5 >= ranks:
+        return 5
     if share >= 4 and groups4 >= ranks:
         return 4
     if share >= 2 and groups2 >= ranks:

@@ -190,7 +190,7 @@ typedef struct dk_stats {
     uint32_t sort_passes;     /* radix passes executed by the last suffix sort */
     uint64_t sorted_elements; /* sum over passes of elements moved */
     uint64_t dc_runs;         /* m of the last dc encode */
-    uint32_t entropy_threads; /* host threads the last range-coder pass used: 1, 2 (models | coder) or 4 (two model halves, merger, coder) */
+    uint32_t entropy_threads; /* host threads the last range-coder pass used: 1, 2 (models | coder), 4 (exponent model, mantissa model, merger, coder) or 5 (the exponent model in two halves) */
     int32_t entropy_l3_group; /* the last-level-cache group that pass claimed for its threads (lowest cpu number in it); -1: none */
     /* per-kernel HIP-event timings accumulated since dk_stats_reset (only while profiling is enabled) */
     uint32_t kernel_launches[DK_NUM_KERNEL_SLOTS];
@@ -228,7 +228,7 @@ const char *dk_kernel_name(int slot);
  * A large single block is coded by a pipeline of 2 or 4 host threads confined to one last-level-cache group; groups are
  * claimed per process, and a process that finds none free codes on one thread.  A launcher of several ranks per node can make that
  * deterministic: ask every rank how many groups it could claim, and set the same form everywhere. */
-/* thread form of the host coding pass, process-wide: 0 automatic (default; or DK_ENTROPY_THREADS at load time) | 1 | 2 | 4 */
+/* thread form of the host coding pass, process-wide: 0 automatic (default; or DK_ENTROPY_THREADS at load time) | 1 | 2 | 4 | 5 */
 int dk_set_entropy_threads(int mode);
 /* number of last-level-cache groups in which the calling thread may use at least min_cores cores */
 int dk_host_l3_groups(int min_cores);

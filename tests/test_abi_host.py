@@ -243,7 +243,7 @@ def _gated_encode(n, init, dist, sym, origin, ready, stall_ms, threads):
     return rc, out[:ln.value].tobytes()
 
 
-@pytest.mark.parametrize("threads", [1, 2, 4])
+@pytest.mark.parametrize("threads", [1, 2, 4, 5])
 def test_stream_that_is_still_arriving(threads):
     """ADVICE r3 (abi.cpp:113): the host coder of a large block starts while the distance stream is still on its way from the GPU and waits
     at a frontier the HIP stream's host functions move.  Here another thread moves the frontier: in steps (same bytes as the finished

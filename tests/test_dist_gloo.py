@@ -102,11 +102,12 @@ def _check_rank_reports(res, world):
     all ranks together, and says so when a rank coded on fewer threads than planned."""
     from dark_amd import entropy
     plan = res["entropy_thread_plan"]
-    assert plan in (1, 2, 4) and [r["rank"] for r in res["ranks"]] == list(range(world))
+    assert plan in (1, 2, 4, 5) and [r["rank"] for r in res["ranks"]] == list(range(world))
     g4 = min(r["l3_groups_with_4_cores"] for r in res["ranks"])
     g2 = min(r["l3_groups_with_2_cores"] for r in res["ranks"])
+    g5 = min(r["l3_groups_with_5_cores"] for r in res["ranks"])
     # deterministic: when there are fewer claimable L3 groups than ranks, ALL ranks drop to the narrower form together
-    assert plan == entropy.plan_threads(g4, g2, world, res["host_cpu_share_per_rank"])
+    assert plan == entropy.plan_threads(g4, g2, world, res["host_cpu_share_per_rank"], g5)
     for r in res["ranks"]:
         assert {"ms_entropy", "ms_per_step", "host_entropy_threads", "l3_group", "stream_bytes"} <= set(r)
         assert 1 <= r["host_entropy_threads"] <= plan
@@ -118,10 +119,11 @@ def _check_rank_reports(res, world):
 def test_thread_plan_is_deterministic():
     from dark_amd import entropy
     assert entropy.plan_threads(16, 16, 8, 8) == 4      # a group of four cores for every rank
+    assert entropy.plan_threads(16, 16, 8, 8, 16) == 5 and entropy.plan_threads(16, 16, 8, 8, 7) == 4 and entropy.plan_threads(16, 16, 8, 4, 16) == 4
     assert entropy.plan_threads(7, 16, 8, 8) == 2       # one rank would lose the race for a 4-core group: everybody takes two threads
     assert entropy.plan_threads(7, 7, 8, 8) == 1
     assert entropy.plan_threads(16, 16, 8, 3) == 2 and entropy.plan_threads(16, 16, 8, 1) == 1  # the CPU share caps the form
-    assert entropy.l3_groups(1) >= entropy.l3_groups(2) >= entropy.l3_groups(4) >= 0
+    assert entropy.l3_groups(1) >= entropy.l3_groups(2) >= entropy.l3_groups(4) >= entropy.l3_groups(5) >= 0
     with pytest.raises(Exception):
         entropy.set_threads(3)
     entropy.set_threads(0)

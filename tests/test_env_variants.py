@@ -143,12 +143,13 @@ def _run(snippet, env, tuning=False):
 
 
 def test_multi_thread_entropy_is_bit_exact():
+    _run(CPU_SNIPPET, {"DK_ENTROPY_THREADS": "5"})
     _run(CPU_SNIPPET, {"DK_ENTROPY_THREADS": "4"})
     _run(CPU_SNIPPET, {"DK_ENTROPY_THREADS": "2"})
     _run(CPU_SNIPPET, {"DK_ENTROPY_THREADS": "1"})
 
 
-@pytest.mark.parametrize("threads", ["1", "2", "4"])
+@pytest.mark.parametrize("threads", ["1", "2", "4", "5"])
 def test_entropy_error_paths_return_codes(threads):
     _run(CPU_ERROR_SNIPPET, {"DK_ENTROPY_THREADS": threads})
 

@@ -25,3 +25,19 @@ def test_host_decoders_under_asan_ubsan(tmp_path):
     assert run.returncode == 0 and "failures 0" in run.stdout, run.stdout[-2000:] + run.stderr[-4000:]
     assert "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr, run.stderr[-4000:]
     shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs the ROCm clang++")
+def test_every_thread_form_codes_the_same_bytes_under_tsan_free_build(tmp_path):
+    """tools/ent_forms_fuzz.cpp: two threads, the four-stage and the five-stage pipeline against one thread on random distance streams of
+    four flavours (tiny, huge with long unary extensions, mostly zero, mixed) -- the halves of the five-stage form must add up to the
+    decision the one-thread model codes (src/model/dark.rs:180-214)."""
+    exe = str(tmp_path / "ent_forms_fuzz")
+    cmd = [CLANG, "-O2", "-std=c++17", "-march=x86-64-v3", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+           os.path.join(ROOT, "tools", "ent_forms_fuzz.cpp"), os.path.join(ROOT, "dark_amd", "csrc", "entropy.cpp"),
+           os.path.join(ROOT, "dark_amd", "csrc", "bbb.cpp"), "-lpthread"]
+    build = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0 and "bad: 0" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
+    shutil.rmtree(tmp_path, ignore_errors=True)
