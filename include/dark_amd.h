@@ -239,7 +239,7 @@ void dk_last_entropy_info(int *threads, int *l3_group);
 /* dk_stream_encode on a distance stream that is still ARRIVING, the way dk_dev_block_encode feeds its host coder while the D2H copies
  * of a large block run: *ready (read atomically; another thread of the caller moves it) = entries of dist / sym that are there.  The
  * coder waits at that frontier; (size_t)-1 there = "the producer gave up", and a frontier that stands still for stall_ms milliseconds
- * (0 = 20 s) = "the stream hangs": DK_E_HIP in both cases instead of a coder that spins for ever.  host_threads: 0 automatic | 1 | 2 | 4. */
+ * (0 = 20 s) = "the stream hangs": DK_E_HIP in both cases instead of a coder that spins for ever.  host_threads: 0 automatic | 1 | 2 | 4 | 5. */
 int dk_dbg_stream_encode_gated(int model_id, size_t n, const uint32_t init[256], const uint32_t *dist, const uint8_t *sym, size_t m,
                                uint32_t origin, uint8_t *out, size_t out_cap, size_t *out_len, const size_t *ready, unsigned stall_ms,
                                int host_threads);
