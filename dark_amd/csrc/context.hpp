@@ -171,6 +171,8 @@ struct SortFinalOut {
 // final_out (may be null; only with the sort of more than 8192 pairs): see SortFinalOut; then `vals` / `vals_alt` are both free on return
 int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&vals, uint32_t *&vals_alt, size_t count,
                int begin_bit, int end_bit, const TextKeys *text = nullptr, const SortFinalOut *final_out = nullptr);
+int sort_groups(dk_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, const uint32_t *starts, size_t ngroups, size_t npairs,
+                uint32_t above, int begin_bit, int end_bit);
 int local_sort_tiles(dk_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, size_t count, int begin_bit, int end_bit);  // experiment hook
 // scratch_b (n u64, may be null): second pair buffer of the LDS-window form (inverse of a permutation of up to 2^27 entries)
 // marked_val (may be null; only honoured by the LDS-window form, see inverse_through_windows): entries of idx with bit 31 set stand for

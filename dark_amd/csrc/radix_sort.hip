@@ -563,7 +563,106 @@ __global__ __launch_bounds__(SS_BLOCK) void k_radix_sort_small(uint64_t *__restr
     }
 }
 
+// Many independent small sorts in one launch: workgroup g sorts the pairs [starts[g], starts[g + 1]) by themselves (k_radix_sort_small's loop) when
+// their number lies in (lo, hi] -- one launch per size class, a workgroup whose range belongs to another class leaves at once.  hi <= BLOCK * 8.
+// The medium groups of the L-first path's big list (lfirst.inc): 257 .. 8192 members each, tens of thousands of them per round.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_sort_groups(const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout,  // (kout may be kin: no __restrict__)
+                                                       const uint32_t *__restrict__ starts, uint32_t lo, uint32_t hi, int begin_bit, int end_bit) {
+    constexpr int WAVES = BLOCK / 64, KPT = 8, MAXN = BLOCK * KPT;
+    const uint32_t start = starts[blockIdx.x], count = starts[blockIdx.x + 1] - start;
+    if (count <= lo || count > hi) return;
+    __shared__ uint64_t s_keys[MAXN];
+    __shared__ uint32_t s_vals[MAXN];
+    __shared__ uint32_t s_cnt[WAVES][256];
+    __shared__ uint32_t s_start[256];
+    __shared__ uint32_t s_tmp[WAVES + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // pairs per thread this group needs (1 .. KPT): every loop below stops there, so a group costs what its size asks for, not what the class allows
+    const int kmax = static_cast<int>((count + BLOCK - 1) / BLOCK);
+    const uint32_t wbase = static_cast<uint32_t>(wave) * (64u * static_cast<uint32_t>(kmax));
+    uint64_t key[KPT];
+    uint32_t val[KPT];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        if (k >= kmax) break;
+        const uint32_t li = wbase + k * 64 + lane;
+        key[k] = li < count ? kin[start + li] : ~0ull;
+        val[k] = li < count ? vin[start + li] : 0u;
+    }
+    for (int shift = begin_bit; shift < end_bit; shift += 8) {
+        for (int i = tid; i < WAVES * 256; i += BLOCK) (&s_cnt[0][0])[i] = 0;
+        __syncthreads();
+        uint32_t rnk[KPT];
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            if (k >= kmax) break;
+            const uint32_t d = digit_of(key[k], shift);
+            const LaneSet same = wave_match<8>(d, ~0ull);
+            const uint32_t before = same.before();
+            const uint32_t old = s_cnt[wave][d];
+            __builtin_amdgcn_wave_barrier();
+            if (before == 0) s_cnt[wave][d] = old + same.count();
+            __builtin_amdgcn_wave_barrier();
+            rnk[k] = old + before;
+        }
+        __syncthreads();
+        {
+            const int d = tid & 255;
+            uint32_t run = 0;
+            if (tid < 256) {
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) {
+                    const uint32_t c = s_cnt[w][d];
+                    s_cnt[w][d] = run;
+                    run += c;
+                }
+            }
+            const uint32_t first = block_excl_sum<WAVES>(tid < 256 ? run : 0u, s_tmp, nullptr);
+            if (tid < 256) s_start[d] = first;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            if (k >= kmax) break;
+            const uint32_t d = digit_of(key[k], shift);
+            const uint32_t p = s_start[d] + s_cnt[wave][d] + rnk[k];
+            s_keys[p] = key[k];
+            s_vals[p] = val[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            if (k >= kmax) break;
+            const uint32_t li = wbase + k * 64 + lane;
+            key[k] = s_keys[li];
+            val[k] = s_vals[li];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        if (k >= kmax) break;
+        const uint32_t li = wbase + k * 64 + lane;
+        if (li < count) { kout[start + li] = key[k]; vout[start + li] = val[k]; }
+    }
+}
+
 }  // namespace
+
+// ngroups independent sorts on key bits [begin_bit, end_bit): group g = the pairs [starts[g], starts[g + 1]) of kin / vin, more than `above` and at
+// most 8192 of them (other sizes are left alone: nothing is written for them); the sorted group goes to the same places of kout / vout (which may be
+// kin / vin themselves).
+int sort_groups(dk_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, const uint32_t *starts, size_t ngroups, size_t npairs,
+                uint32_t above, int begin_bit, int end_bit) {
+    if (ngroups == 0) return DK_OK;
+    hipStream_t st = ctx->stream;
+    LaunchScope ls(ctx, K_RADIX_SORT_SMALL, 24.0 * npairs);
+    k_sort_groups<256><<<dim3(ngroups), dim3(256), 0, st>>>(kin, vin, kout, vout, starts, above, 2048u, begin_bit, end_bit);
+    k_sort_groups<1024><<<dim3(ngroups), dim3(1024), 0, st>>>(kin, vin, kout, vout, starts, std::max(above, 2048u), 8192u, begin_bit, end_bit);
+    DK_HIP(ctx, hipGetLastError());
+    return DK_OK;
+}
 
 // Sorts `count` pairs on key bits [begin_bit, end_bit).  keys/vals are the input buffers, *_alt equally sized scratch;
 // on return `keys` and `vals` refer to whichever buffer holds the sorted data (the references are swapped per pass).

@@ -5,6 +5,7 @@ The device-side switches exist in the TUNING build only (dark_amd/libdark_amd_tu
 product library has them compiled in as constants:
   DK_XCD=0 plain tile order | DK_DIGIT_PLANE=0 / 2 histograms from the keys always / from the digit plane from 2^26 pairs only | DK_PLATEAU=0 general doubling rounds only | DK_PAIR_CHAINS=0 no pair chains in front of the in-place rounds
   DK_BWT_CARRY=0 L gathered from the suffix array instead of riding with the suffixes | DK_PREFIX=0|1|2|3 prefix length of the initial sort
+  DK_LF_MEDIUM=0 the L-first path's big list as one region through the global sort (default: groups of up to 8192 members sorted inside LDS)
   DK_PERIOD=0 never a period round | 2 a period round wherever the probe finds one periodic 64-byte window (the product asks for an eighth of the block)"""
 import os
 import subprocess
@@ -158,7 +159,7 @@ def test_entropy_error_paths_return_codes(threads):
 @pytest.mark.parametrize("env", [{"DK_XCD": "0"}, {"DK_DIGIT_PLANE": "0"}, {"DK_DIGIT_PLANE": "2"}, {"DK_PLATEAU": "0"}, {"DK_BWT_CARRY": "0"},
                                  {"DK_PLATEAU": "0", "DK_BWT_CARRY": "0"}, {"DK_PAIR_CHAINS": "0"}, {"DK_PAIR_CHAINS": "1", "DK_BWT_CARRY": "0"},
                                  {"DK_LFIRST": "0"}, {"DK_LFIRST": "2"}, {"DK_LFIRST": "2", "DK_LF_MAX": "32"}, {"DK_LF_SWITCH": "40"},
-                                 {"DK_LF_SWITCH": "100"}])
+                                 {"DK_LF_SWITCH": "100"}, {"DK_LF_MEDIUM": "0"}, {"DK_LFIRST": "2", "DK_LF_MEDIUM": "0"}])
 def test_gpu_variants_match_oracle(env):
     _run(GPU_SNIPPET, env, tuning=True)
 
