@@ -1622,6 +1622,8 @@ int entropy_thread_mode() { return g_thread_mode.load(std::memory_order_relaxed)
 
 }  // namespace
 
+const uint64_t *reciprocal_table14() { return reciprocal_table(); }
+
 static thread_local int t_last_threads = 1;
 static thread_local int t_last_group = -1;
 int last_entropy_threads() { return t_last_threads; }

@@ -63,14 +63,19 @@ struct RangeState {
     }
 };
 
+const uint64_t *reciprocal_table14();  // [t] = ceil(2^64 / t) for 2 <= t < 2^14 (entropy.cpp)
+
 class Encoder {
 public:
-    Encoder(uint8_t *out, size_t cap) : out_(out), cap_(cap) {}
+    Encoder(uint8_t *out, size_t cap) : out_(out), cap_(cap), inv_(reciprocal_table14()) {}
     // interval [from,to) out of total
     // The models guarantee from < to <= total < 2^14 (frequencies stay >= 1, binary probabilities stay in [1, 4095]) and the
     // coder keeps hi - low > 2^14 between symbols, so r >= 1: the hot path carries no validity branches.
     inline bool put(uint32_t total, uint32_t from, uint32_t to) {
-        const uint32_t r = (rs_.hi - rs_.low) / total;
+        // span / total as the high half of span * ceil(2^64 / total) (exact for span < 2^32, total < 2^15: entropy.cpp, the pipeline's events): the
+        // table entry is known long before the coder's state is, the division waited for it
+        const uint32_t span = rs_.hi - rs_.low;
+        const uint32_t r = (total >= 2u && total < (1u << 14)) ? static_cast<uint32_t>((static_cast<unsigned __int128>(span) * inv_[total]) >> 64) : span / total;
         return emit_narrow(r, from, to);
     }
     // same with total == 1 << shift (bin models with threshold 4096, apm::Bit): the division becomes a shift
@@ -109,6 +114,7 @@ private:
     RangeState rs_;
     uint8_t *out_;
     size_t cap_, len_ = 0;
+    const uint64_t *inv_;
     int err_ = 0;
 };
 
