@@ -143,14 +143,30 @@ __device__ __forceinline__ void load16_le(const uint8_t *__restrict__ t, size_t 
     *lo = a;
     *hi = b;
 }
+// sixteen bytes from any position (zero past the end): two unaligned 8-byte loads where the text has them
+__device__ __forceinline__ void load16_any(const uint8_t *__restrict__ t, size_t n, size_t j, uint64_t *lo, uint64_t *hi) {
+    if (j + 16 <= n) {
+        typedef uint64_t __attribute__((aligned(1))) unaligned_u64;
+        typedef const unaligned_u64 __attribute__((address_space(1))) *gptr8;
+        *lo = *(gptr8)(t + j);
+        *hi = *(gptr8)(t + j + 8);
+        return;
+    }
+    load16_le(t, n, j, lo, hi);
+}
 // bit k of the result: position j + k is a break (T[j+k] != T[j+k+p], or j + k + p >= n); positions at or beyond n are breaks too
 __device__ __forceinline__ uint32_t period_breaks16(const uint8_t *__restrict__ t, size_t n, size_t j, int p) {
     uint64_t w0, w1, w2, w3;
     load16_le(t, n, j, &w0, &w1);
-    load16_le(t, n, j + 16, &w2, &w3);
-    (void)w3;
-    const uint64_t s0 = p == 8 ? w1 : ((w0 >> (8 * p)) | (w1 << (64 - 8 * (p & 7))));
-    const uint64_t s1 = p == 8 ? w2 : ((w1 >> (8 * p)) | (w2 << (64 - 8 * (p & 7))));
+    uint64_t s0, s1;
+    if (p > 8) {  // long periods (k_period_search): the sixteen bytes p further on, wherever they lie
+        load16_any(t, n, j + static_cast<size_t>(p), &s0, &s1);
+    } else {
+        load16_le(t, n, j + 16, &w2, &w3);
+        (void)w3;
+        s0 = p == 8 ? w1 : ((w0 >> (8 * p)) | (w1 << (64 - 8 * (p & 7))));
+        s1 = p == 8 ? w2 : ((w1 >> (8 * p)) | (w2 << (64 - 8 * (p & 7))));
+    }
     const uint64_t x0 = w0 ^ s0, x1 = w1 ^ s1;
     uint32_t m = 0;
 #pragma unroll
@@ -162,6 +178,44 @@ __device__ __forceinline__ uint32_t period_breaks16(const uint8_t *__restrict__ 
     const size_t lim = n >= static_cast<size_t>(p) ? n - p : 0;  // first such position
     if (j + 16 > lim) m |= lim > j ? (0xFFFFu << (lim - j)) & 0xFFFFu : 0xFFFFu;
     return m;
+}
+// Long periods (9 .. PS_MAX: fixed-size records, tables of one row).  The probe above only looks at p <= 8, and the token needs p <= h -- a long
+// period is worth finding only for a block whose doubling rounds would run over everything anyway (giant groups hold most of it), and is used
+// once the depth has reached it.  k_period_search: PS_SAMPLES evenly spread positions, a workgroup each; thread i tests p = 9 + i, 9 + i + 256, ...
+// for 48 equal bytes and the smallest hit of a sample goes to found[sample].  k_period_count: 64-byte windows that follow a given p (any p).
+constexpr int PS_SAMPLES = 32;
+constexpr uint32_t PS_MAX = 1u << 18;
+__global__ __launch_bounds__(256) void k_period_search(const uint8_t *__restrict__ t, size_t n, uint32_t pmax, uint32_t *__restrict__ found) {
+    const size_t x = (2 * static_cast<size_t>(blockIdx.x) + 1) * n / (2 * PS_SAMPLES);
+    if (x + pmax + 48 > n) return;  // (found[] was set to ~0: no answer from this sample)
+    uint64_t a[6];
+    for (int k = 0; k < 6; k += 2) load16_any(t, n, x + 8 * k, &a[k], &a[k + 1]);
+    for (uint32_t p = 9 + threadIdx.x; p <= pmax; p += 256) {
+        if (p >= found[blockIdx.x]) break;  // (a smaller hit exists already)
+        uint64_t b[6];
+        for (int k = 0; k < 6; k += 2) load16_any(t, n, x + p + 8 * k, &b[k], &b[k + 1]);
+        if (((a[0] ^ b[0]) | (a[1] ^ b[1]) | (a[2] ^ b[2]) | (a[3] ^ b[3]) | (a[4] ^ b[4]) | (a[5] ^ b[5])) == 0) {
+            atomicMin(&found[blockIdx.x], p);
+            break;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_period_count(const uint8_t *__restrict__ t, size_t n, uint32_t p, uint32_t *__restrict__ count) {
+    const size_t w = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t p0 = w * 64;
+    bool ok = false;
+    if (p0 + 64 + p <= n) {
+        uint64_t diff = 0;
+        for (int k = 0; k < 4; ++k) {
+            uint64_t a0, a1, b0, b1;
+            load16_any(t, n, p0 + 16 * k, &a0, &a1);
+            load16_any(t, n, p0 + p + 16 * k, &b0, &b1);
+            diff |= (a0 ^ b0) | (a1 ^ b1);
+        }
+        ok = diff == 0;
+    }
+    const uint32_t c = static_cast<uint32_t>(__popcll(__ballot(ok)));
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
 }
 constexpr uint32_t PB_NONE = 0xFFFFFFFFu;
 // thread tid takes the tile's chunk 255 - tid: an exclusive running max over the threads in tid order then covers the chunks BEHIND its own
@@ -1814,6 +1868,7 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
     //     of a group must share the period string itself), every suffix inside such a stretch is placed by where the stretch ends -- a^n b,
     //     (ab)^n, zero padding: one round instead of log2(length) doubling rounds over all of them.  The rank array's buffer holds the
     //     next-break positions (it is built later).
+    bool small_period_round = false;
     if (active > 0 && period_mode != 0) {
         const uint32_t *pc = ctx->h_mail + 16 + 258;
         const int pmax = static_cast<int>(std::min<uint64_t>(8, h));
@@ -1824,6 +1879,7 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
             for (int q = 1; q <= pmax && !period; ++q)
                 if (static_cast<uint64_t>(pc[q - 1]) * 10 >= static_cast<uint64_t>(cmax) * 9) period = q;
         if (period) {
+            small_period_round = true;
             const size_t ptiles = div_up(n, PB_TILE);
             const size_t mark2 = ctx->ws_mark();
             uint32_t *tile_first = ctx->ws_alloc<uint32_t>(ptiles);
@@ -1879,10 +1935,70 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
         have_ranks = true;
     }
 
+    // 5c'. a long period (9 .. 2^18: fixed-size records, a table of one row)?  Looked for only where giant groups hold most of what is active --
+    //      doubling would run over everything for log2(n / h) rounds -- and used by one period round (4b's, with the tokens of this period) as
+    //      soon as the depth covers it: period 1000 x 8000 (8 MB) 21 -> 9 rounds.
+    uint32_t long_period = 0;
+    if (period_mode != 0 && !small_period_round && active > 0 && nbig * 2 > active && n >= (1u << 16)) {
+        uint32_t *d_found = ctx->d_mail + 320;  // PS_SAMPLES words + 1 counter (words 300 .. 304 are the prefix probe's)
+        const uint32_t pmax = static_cast<uint32_t>(std::min<uint64_t>(PS_MAX, n / 4));
+        DK_HIP(ctx, hipMemsetAsync(d_found, 0xFF, PS_SAMPLES * sizeof(uint32_t), st));
+        DK_HIP(ctx, hipMemsetAsync(d_found + PS_SAMPLES, 0, sizeof(uint32_t), st));
+        {
+            LaunchScope ls(ctx, K_PERIOD, 0.0);
+            k_period_search<<<dim3(PS_SAMPLES), dim3(256), 0, st>>>(d_text, n, pmax, d_found);
+        }
+        DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 320, d_found, PS_SAMPLES * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        DK_HIP(ctx, hipStreamSynchronize(st));
+        uint32_t best = 0, best_votes = 0;  // the period most samples agree on
+        for (int a = 0; a < PS_SAMPLES; ++a) {
+            const uint32_t v = ctx->h_mail[320 + a];
+            if (v == 0xFFFFFFFFu) continue;
+            uint32_t votes = 0;
+            for (int b2 = 0; b2 < PS_SAMPLES; ++b2) votes += ctx->h_mail[320 + b2] == v ? 1u : 0u;
+            if (votes > best_votes || (votes == best_votes && v < best)) { best = v; best_votes = votes; }
+        }
+        if (best_votes >= PS_SAMPLES / 4) {
+            {
+                LaunchScope ls(ctx, K_PERIOD, 2.0 * n);
+                k_period_count<<<dim3(div_up(div_up(n, 64), 256)), dim3(256), 0, st>>>(d_text, n, best, d_found + PS_SAMPLES);
+            }
+            DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 320 + PS_SAMPLES, d_found + PS_SAMPLES, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            DK_HIP(ctx, hipStreamSynchronize(st));
+            // three quarters of the block: a Fibonacci word follows "period 55" in 47 % of its windows, in stretches of a few hundred symbols that one
+            // round on their ends does not settle (6.35 against 5.71 ms at 4 MB)
+            if (static_cast<uint64_t>(ctx->h_mail[320 + PS_SAMPLES]) * 64 * 4 >= static_cast<uint64_t>(n) * 3) long_period = best;
+            if (trace)
+                fprintf(stderr, "[dk] long period: %u of %d samples say %u, %u of %zu windows follow it -> %s\n", best_votes, PS_SAMPLES, best, ctx->h_mail[320 + PS_SAMPLES], n / 64,
+                        long_period ? "a period round once the depth covers it" : "not used");
+        }
+    }
     // 5c. doubling rounds: the general form while big groups exist, ...
     const bool plateau_enabled = DK_KNOB("DK_PLATEAU", 1) != 0;
     while (active > 0 && (nmedium > 0 || !plateau_enabled)) {
         if (ctx->stats.rounds > 44) return ctx->fail(DK_E_INTERNAL, "suffix_array: no convergence after 44 rounds");
+        if (long_period && h >= long_period) {
+            // (next-break positions: the suffix array's buffer when the caller wants L -- nobody reads SA once the ranks exist -- else workspace, if it has room)
+            const size_t mark2 = ctx->ws_mark();
+            uint32_t *nb = carry_bwt ? d_sa : ctx->ws_try_alloc<uint32_t>(n);
+            const size_t ptiles = div_up(n, PB_TILE);
+            uint32_t *tile_first = nb ? ctx->ws_try_alloc<uint32_t>(ptiles) : nullptr;
+            const uint32_t p_now = long_period;
+            long_period = 0;
+            if (nb && tile_first) {
+                {
+                    LaunchScope ls(ctx, K_PERIOD, 2.0 * n + 4.0 * n);
+                    k_period_first<<<dim3(ptiles), dim3(256), 0, st>>>(d_text, static_cast<uint32_t>(n), static_cast<int>(p_now), tile_first);
+                    k_period_spine<<<dim3(1), dim3(1024), 0, st>>>(tile_first, ptiles);
+                    k_period_fill<<<dim3(ptiles), dim3(256), 0, st>>>(d_text, static_cast<uint32_t>(n), static_cast<int>(p_now), tile_first, nb);
+                }
+                DK_HIP(ctx, hipGetLastError());
+                DK_TRY(run_round(8, nullptr, static_cast<int>(p_now), nb));
+                ctx->ws_release(mark2);
+                continue;
+            }
+            ctx->ws_release(mark2);
+        }
         DK_TRY(run_round(0, nullptr));
         h *= 2;
         DK_TAKE_OVER();

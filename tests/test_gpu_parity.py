@@ -51,21 +51,28 @@ def test_sort_pairs(ctx):
         assert first_diff(k2, keys[order]) is None, (count, lo, hi)
 
 
+def _fib_word(n):
+    a, b = b"a", b"ab"
+    while len(b) < n:
+        a, b = b, b + a
+    return np.frombuffer(b[:n], np.uint8)
+
+
 def test_five_megabyte_blocks(orc):
     """blocks above 2^22 bytes: the prefix probe picks the key length and the rank array is built through LDS windows -- text, {A,C,G,T},
-    random bytes, a period-2 block, two identical halves and a period-12 block"""
+    random bytes, a period-2 block, two identical halves and a Fibonacci word"""
     from dark_amd import datagen
     rng = np.random.default_rng(3)
     n = 5_000_011
     cases = [datagen.wiki_like(n, 7), datagen.acgt(n, 8), datagen.random_bytes(n, 9), np.frombuffer(b"ab" * (n // 2) + b"a", np.uint8),
-             np.concatenate([datagen.wiki_like(n // 2, 10)] * 2), np.frombuffer(b"abcdefghijkl" * (n // 12), np.uint8)]
+             np.concatenate([datagen.wiki_like(n // 2, 10)] * 2), _fib_word(n)]
     # what each case must have gone through: (suffix array call, BWT call)
     routes = [({"isa_windows", "text_round", "inplace_rounds", "pair_chains"}, {"lfirst", "lfirst_deep"}),   # text: long repeats end as pair chains / deep groups
               ({"short_prefix", "narrow_keys", "text_round"}, {"short_prefix", "narrow_keys"}),              # {A,C,G,T}: the probe shortens the key
               ({"short_prefix", "narrow_keys"}, {"short_prefix", "narrow_keys"}),                            # random bytes
               ({"period_round", "big_groups"}, {"period_round"}),                                             # period 2: one round on the tokens of the stretch's end
               ({"isa_windows", "inplace_rounds"}, {"lfirst", "lfirst_deep"}),                                 # two identical halves
-              ({"isa_windows", "isa_marked", "general_round", "big_groups"}, {"general_round"})]              # period 12 (longer than the period round looks): giant groups, doubling
+              ({"isa_windows", "isa_marked", "general_round", "big_groups"}, {"general_round"})]              # Fibonacci word (repetitive, no period to find): giant groups, doubling
     with dark_amd.Context(n) as c:
         for t, (sa_route, bwt_route) in zip(cases, routes):
             t = np.ascontiguousarray(t)
@@ -604,8 +611,11 @@ def test_period_round_settles_periodic_blocks_in_one_round(orc):
     abc[n // 2] = ord("b")
     words = np.tile(np.array([0, 0, 1, 7], np.uint8), n // 4 + 1)[:n].copy()
     words[123_456] = 9
+    rows = np.tile(np.random.default_rng(5).integers(0, 256, 1000, dtype=np.uint8), n // 1000 + 1)[:n].copy()  # a table of one 1000-byte row: the long-period
+    rows[n // 3] ^= 1                                                                                            # search finds it, the token round waits for depth 1000
     cases = {"a^n b": np.concatenate([np.zeros(n - 1, np.uint8), np.ones(1, np.uint8)]), "(ab)^n": np.frombuffer(b"ab" * (n // 2), np.uint8),
-             "b^n a": np.concatenate([np.full(n - 1, 98, np.uint8), np.full(1, 97, np.uint8)]), "(abc)^n, one odd byte": abc, "words, one odd": words}
+             "b^n a": np.concatenate([np.full(n - 1, 98, np.uint8), np.full(1, 97, np.uint8)]), "(abc)^n, one odd byte": abc, "words, one odd": words,
+             "rows of 1000 bytes, one odd byte": rows}
     with dark_amd.Context(n) as c:
         for name, t in cases.items():
             t = np.ascontiguousarray(t)
@@ -613,7 +623,7 @@ def test_period_round_settles_periodic_blocks_in_one_round(orc):
             got = c.suffix_array(t)
             assert first_diff(got, want) is None, (name, first_diff(got, want))
             st = c.stats()
-            assert "period_round" in st["routes"] and st["rounds"] <= 3, (name, st["rounds"], st["routes"])
+            assert "period_round" in st["routes"] and st["rounds"] <= (12 if name.startswith("rows") else 3), (name, st["rounds"], st["routes"])
             wb, wo = orc.bwt_forward(t, want)
             bwt, origin = c.bwt_forward(t)
             assert origin == wo and first_diff(bwt, wb) is None, name

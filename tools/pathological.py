@@ -43,6 +43,7 @@ def cases(mode):
             "ab*5e7 (1e8 bytes, period 2)": lambda: np.frombuffer(b"ab" * 50_000_000, np.uint8),
             "two identical 50 MB halves (1e8 bytes)": lambda: np.concatenate([half, half]),
             "a^n b 1e8": lambda: np.concatenate([np.zeros(100_000_000 - 1, np.uint8), np.ones(1, np.uint8)]),
+            "period 1000 x 100000 (1e8 bytes)": lambda: np.tile(np.random.default_rng(1).integers(0, 256, 1000, dtype=np.uint8), 100_000),
             "text with a 3000-byte run of zeros (1e8 bytes)": lambda: np.concatenate([half, np.zeros(3000, np.uint8), half[:50_000_000 - 3000][::-1]]),
         })
     return out

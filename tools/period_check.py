@@ -44,6 +44,12 @@ def make_case(rng, kind, n):
         k = n // 10
         t[rng.integers(0, n, k)] = rng.integers(1, 256, k, dtype=np.uint8)
         return t
+    if kind == 5:    # one long period (9 .. 5000) over the whole block, a few odd bytes (long-period search, token round once the depth covers it)
+        u = rng.integers(0, 256, int(rng.choice([9, 12, 100, 1000, 4999])), dtype=np.uint8)
+        t = np.tile(u, n // len(u) + 1)[:n].copy()
+        for _ in range(int(rng.integers(0, 4))):
+            t[int(rng.integers(0, n))] = rng.integers(0, 256)
+        return t
     # kind 4: bytes 0 and 255 (the token's direction at both ends of the alphabet), runs ending at the block's end
     t = rng.choice(np.array([0, 255], np.uint8), n, p=[0.9, 0.1])
     t[-int(rng.integers(1, 300)):] = rng.choice(np.array([0, 255], np.uint8))
@@ -59,7 +65,7 @@ def main():
     bad = 0
     with dark_amd.Context(1 << 23) as ctx:
         for c in range(ncases):
-            kind = c % 5
+            kind = c % 6
             n = int(rng.choice([5000, 70000, 300000, 1 << 20, 3_000_000, (1 << 22) + 77]))
             t = np.ascontiguousarray(make_case(rng, kind, n))
             n = len(t)
