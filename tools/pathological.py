@@ -6,7 +6,7 @@ does not have.
 
 small: the 4-16 MB cases rounds 1 and 2 measured (gpurun_out/patho.log, r2_patho.log).  full: the same plus 1e8-byte cases -- period-2
 text and two identical 50 MB halves of wiki-like text.  One JSON object per case on stdout (and collected into out.json): MB/s of the
-device suffix sort + BWT (input resident in HBM), rounds, radix passes, and whether SA equals the oracle's (TEST INFRASTRUCTURE use of
+device suffix sort + BWT (input resident in HBM; `suffix_array_ms`: the suffix array itself, dk_dev_suffix_array), rounds, radix passes, and whether SA equals the oracle's (TEST INFRASTRUCTURE use of
 the oracle: this is a checker tool, like tests/)."""
 import json
 import os
@@ -67,14 +67,17 @@ def main():
                 dt = time.perf_counter() - t0
                 if best is None or dt < best:
                     best, st = dt, ctx.stats()
+            t_sa0 = time.perf_counter()
             ctx.dev_suffix_array(d_in, n, d_sa)
+            sa_ms = 1e3 * (time.perf_counter() - t_sa0)
+            sa_st = ctx.stats()
             t1 = time.perf_counter()
             want = orc.sa_sais(t)
             dto = time.perf_counter() - t1
             want_bwt, want_origin = orc.bwt_forward(t, want)
             ok = bool((d_sa.cpu().numpy().view(np.uint32) == want).all()) and origin == want_origin and bool((d_bwt.cpu().numpy() == want_bwt).all())
             res = {"case": name, "bytes": n, "gpu_ms": round(1e3 * best, 2), "gpu_MBps": round(n / best / 1e6, 1), "rounds": st["rounds"],
-                   "bwt_routes": sorted(st["routes"]),
+                   "bwt_routes": sorted(st["routes"]), "suffix_array_ms": round(sa_ms, 2), "suffix_array_rounds": sa_st["rounds"],
                    "sort_passes": st["sort_passes"], "oracle_sais_s": round(dto, 2), "oracle_MBps": round(n / dto / 1e6, 1), "equal_to_oracle": ok}
             print(json.dumps(res), flush=True)
             results.append(res)
