@@ -1,3 +1,5 @@
+"""A 300 MB text block (above 2^27 suffixes: the L-first path, the LDS-window inverse permutation's third split level, the five-stage host coder on
+300 M distances) against the oracle: BWT + origin, then encode -> decode.   python tools/big_block_check.py   (TEST INFRASTRUCTURE use of the oracle)"""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
 import torch, dark_amd
