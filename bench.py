@@ -48,6 +48,8 @@ def parse():
                          "workload's size (--n overrides); \"data\": \"real\".  Without it, $DARK_CORPUS_DIR/{book1,enwik8,enwik9} is used when the workload "
                          "is that corpus's stand-in and the file exists")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-host-input", action="store_true",
+                    help="skip the host_input leg (dk_block_encode from host memory: the H2D copy inside the timed region, beside the headline)")
     ap.add_argument("--pipeline-blocks", type=int, default=15,
                     help="extra leg: this many blocks in flight on one GPU, device stages pipelined against host coding (0 = skip)")
     ap.add_argument("--pipeline-threads", type=int, default=15)
@@ -409,6 +411,39 @@ def main():
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed_max = float(tmax.item())
+
+    # host_input leg: where the reference's encode starts (the block in host memory: src/main.rs:87-95 -> src/block/dc.rs:41; SURVEY 8(d)
+    # "end-to-end ... including H2D/D2H").  dk_block_encode from pinned and from pageable host memory, the H2D copy inside the timed region,
+    # same barrier / max-over-ranks protocol; reported beside the headline, never as `value` (whose input is resident in HBM).
+    host_input = None
+    if not args.no_host_input:
+        hsteps = max(1, min(args.steps, 5))
+        host_input = {"steps": hsteps}
+        try:
+            pinned = torch.from_numpy(block).pin_memory()
+            sources = (("pinned", pinned.numpy()), ("pageable", block))
+        except RuntimeError as e:  # (no pinned memory to be had: the pageable form alone)
+            host_input["pinned_error"] = str(e)
+            sources = (("pageable", block),)
+        for label, arr in sources:
+            ctx.block_encode_into(args.model, arr, out_buf)
+            acc = {}
+            barrier()
+            th = time.perf_counter()
+            for _ in range(hsteps):
+                s2 = ctx.block_encode_into(args.model, arr, out_buf)
+                st = ctx.stats()
+                for k in ("ms_h2d", "ms_sa", "ms_bwt", "ms_dc", "ms_d2h", "ms_entropy", "ms_total"):
+                    acc[k] = acc.get(k, 0.0) + st[k] / hsteps
+            barrier()
+            th = torch.tensor([time.perf_counter() - th], dtype=torch.float64, device=dev)
+            if use_dist:
+                dist.all_reduce(th, op=dist.ReduceOp.MAX)
+            host_input[label] = {"MBps": round(world * n * hsteps / float(th.item()) / 1e6, 3), "ms_per_step": round(1e3 * float(th.item()) / hsteps, 3),
+                                 "stage_ms": {kk: round(v, 3) for kk, v in acc.items()},
+                                 "h2d_GBs": round(n / (acc["ms_h2d"] * 1e-3) / 1e9, 1) if acc["ms_h2d"] > 0 else None,
+                                 "stream_identical": bool(s2.tobytes() == stream.tobytes())}
+        del sources
     # every rank's view of its own timed steps, for rank 0's line: a rank that fell back to fewer coding threads shows here
     mine = rank_report(rank, args.steps, elapsed, stage_acc, threads_seen, groups_seen, groups, n, len(stream))
     if use_dist:
@@ -616,7 +651,11 @@ def main():
             "decode_MBps": None if decode_mbps is None else round(decode_mbps, 3),
             "roundtrip_ok": roundtrip_ok,
             "compressed_bytes": int(len(stream)), "ratio": round(len(stream) / n, 4),
-            "stage_ms": {kk: round(v, 3) for kk, v in per.items()},
+            "value_host_input_MBps": None if not host_input or "pinned" not in host_input else host_input["pinned"]["MBps"],
+            "host_input": host_input,
+            # (ms_h2d: the H2D copy of the host_input leg's pinned form -- the timed steps of `value` start with the block in HBM and have none)
+            "stage_ms": {**{kk: round(v, 3) for kk, v in per.items()},
+                         "ms_h2d": None if not host_input or "pinned" not in host_input else host_input["pinned"]["stage_ms"]["ms_h2d"]},
             "stage_ms_unprofiled": {kk: round(v, 3) for kk, v in clean_acc.items()},
             "sa_rounds": stats["rounds"], "sort_passes": stats["sort_passes"], "dc_runs": stats["dc_runs"],
             "host_entropy_threads": stats["entropy_threads"], "host_cpu_share_per_rank": share,

@@ -141,6 +141,14 @@ class Context:
         self._ck(self._lib.dk_block_encode(self._h, mid, _ptr(t), n, _ptr(out), cap, C.byref(ln)))
         return out[:ln.value].tobytes()
 
+    def block_encode_into(self, model, data, out):
+        """dk_block_encode with a caller-owned output array (no copy of the stream): `data` is host memory -- pageable or pinned --
+        and the H2D copy is part of the call (stats()["ms_h2d"]); returns a view of `out`"""
+        t = as_u8(data)
+        ln = C.c_size_t(0)
+        self._ck(self._lib.dk_block_encode(self._h, model_id(model), _ptr(t), len(t), _ptr(out), len(out), C.byref(ln)))
+        return out[:ln.value]
+
     def block_decode(self, model, stream, n):
         s = as_u8(stream)
         out = np.empty(n, dtype=np.uint8)

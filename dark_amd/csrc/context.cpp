@@ -80,9 +80,11 @@ void dk_ctx::prof_end() {
 void dk_ctx::prof_collect() {
     if (ev_pending.empty()) return;
     (void)hipStreamSynchronize(stream);
+    const bool each = DK_KNOB("DK_TRACE_LAUNCHES", 0) != 0;  // (tuning build: every bracketed launch in order, for tools/kernel_breakdown.py)
     for (const Pending &p : ev_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            if (each) fprintf(stderr, "[dk] launch %-20s %9.3f us\n", dk::kernel_slot_name(p.slot), 1e3 * ms);
             stats.kernel_ms[p.slot] += ms;
             stats.kernel_bytes[p.slot] += p.bytes;
             stats.kernel_launches[p.slot] += 1;

@@ -13,7 +13,7 @@ cd /tmp
 OUT=$ROOT/gpurun_out/prof_$WL
 rm -rf $OUT
 mkdir -p $OUT
-ARGS="--workload $WL --steps $STEPS --warmup $WARM --no-cpu-baseline --pipeline-blocks 0 --no-decode --no-rccl-selftest"
+ARGS="--workload $WL --steps $STEPS --warmup $WARM --no-cpu-baseline --pipeline-blocks 0 --no-decode --no-rccl-selftest --no-host-input"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py $ARGS > $OUT/bench_profiled.json 2> $OUT/stats.err
 echo "$WL kernel-trace pass done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_FETCH_SIZE -- python3 $ROOT/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1
