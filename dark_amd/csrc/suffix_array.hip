@@ -1714,13 +1714,24 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
             if (static_cast<uint64_t>(pc[q - 1]) * 10 >= static_cast<uint64_t>(cmax) * 9) lf_period = q;
     }
     const bool lf_runs_ok = lf_period > 0 ? !run_heavy : !long_run;
-    if (carry_bwt && allow_lfirst && lf_mode != 0 && (lf_mode == 2 || (n >= (1u << 16) && probe_big_share <= 0.6 && !short_prefix && lf_runs_ok))) {
-        const LfBuffers b{keys_alt, keys_3, vals_3, vals, rank, sym_alt, vals_alt, pos, gid, sym, gstart, bigidx, bigoff};
+    if (carry_bwt && allow_lfirst && lf_mode != 0 && n >= 64 && (lf_mode == 2 || (n >= (1u << 16) && probe_big_share <= 0.6 && !short_prefix && lf_runs_ok))) {
+        // (the arena of the deep groups: the second list buffers of the suffix-array path, which this path does not use, and the upper half of the
+        //  initial keys' buffer -- the lower half holds the next-break positions of a token round)
+        //  initial keys' buffer -- 8 n bytes: [0, 4 n) the next-break positions of a round with tokens, [4 n, 5 n) the arena's symbols, then the depth of every
+        //  group (n / 2 + 2 words) and of every big group (n / 32 + 2 words)
+        uint8_t *kb8 = reinterpret_cast<uint8_t *>(keys);
+        uint32_t *gdepth = reinterpret_cast<uint32_t *>(kb8 + ((5 * n + 15) & ~size_t(15)));
+        const LfBuffers b{keys_alt, keys_3, vals_3, vals, rank, sym_alt, vals_alt, pos, gid, sym, gstart, bigidx, bigoff, pos_alt, gid_alt, kb8 + 4 * n, gdepth, gdepth + n / 2 + 2};
         bool done = false, pristine = true;
         route |= DK_ROUTE_LFIRST;
         // (the initial keys are read by the first rerank only: their buffer holds the next-break positions of a token round later)
+        // tokens in the first round (instead of after the first stalled one) where a thousandth of the block lies inside runs of one byte value or in
+        // periodic 64-byte windows: indentation and rulers in real text
+        const uint32_t *pc = ctx->h_mail + 16 + 258;
+        const bool tokens_early = lf_period > 0 && DK_KNOB("DK_LF_TOKENS_EARLY", 1) != 0 &&
+                                  (static_cast<double>(ctx->h_mail[16 + 257]) * 16.0 > 0.001 * static_cast<double>(n) || static_cast<double>(pc[lf_period - 1]) * 64.0 > 0.001 * static_cast<double>(n));
         DK_TRY(lfirst_path(ctx, d_text, n, keys, key_shift, narrow_keys ? d_starts : nullptr, d_sa, d_bwt, d_origin, b, static_cast<uint32_t>(spk_sort), trace, lf_mode == 2, &done, &pristine,
-                           nullptr, lf_period, reinterpret_cast<uint32_t *>(keys)));
+                           nullptr, lf_period, reinterpret_cast<uint32_t *>(keys), tokens_early));
         if (done) {
             ctx->ws_release(mark);
             *bwt_written = true;
@@ -1844,7 +1855,9 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
         // buffers: everything but the current list is free between rounds; the key buffer that is not a sort's ping-pong partner holds the
         // big list's second suffix array and its symbols (4 n + n of its 8 n bytes); the rank array becomes the big list's positions
         uint32_t *spare = reinterpret_cast<uint32_t *>(keys);
-        const LfBuffers b{keys_alt, keys_3, vals_3, spare, rank, reinterpret_cast<uint8_t *>(spare + n), vals_alt, pos_alt, gid_alt, sym_alt, gstart, bigidx, bigoff};
+        // (the arena of the deep groups: the caller's own list, free once the first rerank has filtered it)
+        uint32_t *gdepth = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(keys) + ((5 * n + 15) & ~size_t(15)));  // (behind the big list's symbols, see above)
+        const LfBuffers b{keys_alt, keys_3, vals_3, spare, rank, reinterpret_cast<uint8_t *>(spare + n), vals_alt, pos_alt, gid_alt, sym_alt, gstart, bigidx, bigoff, vals, pos, sym, gdepth, gdepth + n / 2 + 2};
         const LfFrom from{vals, pos, gid, sym, active};
         bool done = false, pristine = true;
         if (trace) fprintf(stderr, "[dk] %zu active, %zu of them in big groups, depth %llu: the L-first path takes over\n", active, nbig, (unsigned long long)h);
