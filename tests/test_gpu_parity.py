@@ -536,9 +536,13 @@ def test_lfirst_bwt_without_the_suffix_array(orc):
     t[300_000:300_000 + 5000] = 65  # a run of 5000 equal bytes: one group that never splits on text -- it rides in the big list until the round
     cases.append(("a run inside text", t, {"lfirst", "lfirst_big_round", "period_round"}))  # stalls, then one token round places it by where the run ends
     t = base[:1_000_000].copy()
-    for o in range(0, 900_000, 30_000):  # thirty runs of 700 bytes, 2 % of the block: more than the L-first path takes (run probe): suffix-array path
-        t[o + 100:o + 800] = 65
-    cases.append(("many runs inside text", t, {"general_round"}))
+    for o in range(0, 900_000, 30_000):  # thirty runs of 700 bytes, 2 % of the block: tokens in the first round place them by where they end (round 5;
+        t[o + 100:o + 800] = 65          # until then the run probe sent such a block the suffix-array way)
+    cases.append(("many runs inside text", t, {"lfirst", "period_round"}))
+    t = base[:1_000_000].copy()
+    for o in range(0, 900_000, 30_000):  # thirty runs of 2400 bytes, 7 % of the block: more than the L-first path takes (run probe): suffix-array path
+        t[o + 100:o + 2500] = 65
+    cases.append(("a lot of runs inside text", t, {"general_round"}))
     t = base[:1_000_000].copy()
     for k, o in enumerate(range(0, 900_000, 100_000)):  # nine runs of the same length with the same byte behind them: the tokens tie, the rounds go on
         t[o + 100:o + 500] = 66
