@@ -261,7 +261,7 @@ def stub_exchange(args, world, rank):
     return 0
 
 
-def rank_report(rank, steps, elapsed, stage_acc, threads_seen, groups_seen, groups_visible, n, stream_bytes):
+def rank_report(rank, steps, elapsed, stage_acc, threads_seen, groups_seen, groups_visible, n, stream_bytes, numa=(None, None)):
     """what one rank knows about its own timed steps (gathered on rank 0 and printed under "ranks")"""
     return {"rank": rank, "block_bytes": int(n), "stream_bytes": int(stream_bytes), "ms_per_step": round(1e3 * elapsed / steps, 3),
             "ms_entropy": round(stage_acc.get("ms_entropy", 0.0) / steps, 3),
@@ -269,6 +269,9 @@ def rank_report(rank, steps, elapsed, stage_acc, threads_seen, groups_seen, grou
             "host_entropy_threads": min(threads_seen) if threads_seen else None,
             "host_entropy_threads_max": max(threads_seen) if threads_seen else None,
             "l3_group": groups_seen[-1] if groups_seen else None,
+            # memory node of the L3 group the coder claimed, and of the rank's GPU (the coder looks there first: with eight ranks on two sockets a
+            # group across the socket link reads its pinned staging remotely); -1 / None: unknown
+            "l3_group_numa": numa[0], "gpu_numa": numa[1],
             "l3_groups_with_4_cores": int(groups_visible[0]), "l3_groups_with_2_cores": int(groups_visible[1]),
             "l3_groups_with_5_cores": int(groups_visible[2]) if len(groups_visible) > 2 else 0}
 
@@ -391,6 +394,7 @@ def main():
             stage_acc[k] = stage_acc.get(k, 0.0) + st[k]
         threads_seen.append(int(st["entropy_threads"]))
         groups_seen.append(int(st["entropy_l3_group"]))
+        numa_seen = (int(st["entropy_l3_numa"]), int(st["gpu_numa"]))
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.set_profiling(False)
@@ -445,7 +449,7 @@ def main():
                                  "stream_identical": bool(s2.tobytes() == stream.tobytes())}
         del sources
     # every rank's view of its own timed steps, for rank 0's line: a rank that fell back to fewer coding threads shows here
-    mine = rank_report(rank, args.steps, elapsed, stage_acc, threads_seen, groups_seen, groups, n, len(stream))
+    mine = rank_report(rank, args.steps, elapsed, stage_acc, threads_seen, groups_seen, groups, n, len(stream), numa_seen)
     if use_dist:
         reports = [None] * world
         dist.all_gather_object(reports, mine, group=host_group)

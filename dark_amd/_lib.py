@@ -21,7 +21,7 @@ class Stats(C.Structure):
                 ("rounds", C.c_uint32), ("sort_passes", C.c_uint32), ("sorted_elements", C.c_uint64),
                 ("dc_runs", C.c_uint64), ("entropy_threads", C.c_uint32), ("entropy_l3_group", C.c_int32),
                 ("kernel_launches", C.c_uint32 * NUM_KERNEL_SLOTS), ("kernel_ms", C.c_double * NUM_KERNEL_SLOTS),
-                ("kernel_bytes", C.c_double * NUM_KERNEL_SLOTS), ("sa_route", C.c_uint32), ("reserved_", C.c_uint32),
+                ("kernel_bytes", C.c_double * NUM_KERNEL_SLOTS), ("sa_route", C.c_uint32), ("entropy_l3_numa", C.c_int16), ("gpu_numa", C.c_int16),
                 ("ws_peak_bytes", C.c_uint64), ("ws_size_bytes", C.c_uint64)]
 ROUTES = {"short_prefix": 0x1, "narrow_keys": 0x2, "text_round": 0x4, "isa_windows": 0x8, "isa_marked": 0x10, "isa_buckets": 0x20,
           "general_round": 0x40, "big_groups": 0x80, "inplace_rounds": 0x100, "pair_chains": 0x200, "lfirst": 0x400,
@@ -75,6 +75,8 @@ SIGNATURES = {
     "dk_set_entropy_threads": (_i, [_i]),
     "dk_host_l3_groups": (_i, [_i]),
     "dk_last_entropy_info": (None, [C.POINTER(_i), C.POINTER(_i)]),
+    "dk_set_entropy_numa_node": (None, [_i]),
+    "dk_dbg_l3_claim_order": (_i, [C.POINTER(_i), _i, _i, _i, C.POINTER(_i)]),
     "dk_dbg_stream_encode_gated": (_i, [_i, _sz, _vp, _vp, _vp, _sz, C.c_uint32, _vp, _sz, _szp, _vp, C.c_uint, _i]),
     "dk_dbg_sort_pairs": (_i, [_vp, _vp, _vp, _sz, _i, _i]),
     "dk_dbg_dev_sort_pairs": (_i, [_vp, _vp, _vp, _sz, _i, _i]),

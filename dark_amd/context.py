@@ -257,7 +257,7 @@ class Context:
         self._ck(self._lib.dk_get_stats(self._h, C.byref(st)))
         out = {k: getattr(st, k) for k in ("ms_h2d", "ms_sa", "ms_bwt", "ms_dc", "ms_d2h", "ms_entropy", "ms_ibwt",
                                            "ms_total", "rounds", "sort_passes", "sorted_elements", "dc_runs",
-                                           "entropy_threads", "entropy_l3_group", "ws_peak_bytes", "ws_size_bytes")}
+                                           "entropy_threads", "entropy_l3_group", "entropy_l3_numa", "gpu_numa", "ws_peak_bytes", "ws_size_bytes")}
         kernels = {}
         for i in range(_lib.NUM_KERNEL_SLOTS):
             name = self._lib.dk_kernel_name(i)

@@ -1,5 +1,7 @@
 // extern "C" boundary (include/dark_amd.h).  Thin: argument checks, workspace carving, stage sequencing, timing.
 #include <algorithm>
+#include <cctype>
+#include <cstdio>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -49,14 +51,17 @@ size_t workspace_bytes(size_t max_n) {
     //   suffix sort: keys x3 24 n, suffix lists x3 12 n, rank 4 n, slot positions x2 8 n, group ids x2 8 n,
     //                gstart + bigidx 4 n, big-group offsets n / 8, symbols in front x2 2 n            = 62.1 n
     //   on top of that, one of (never two at a time: each is released before the next is taken)
-    //     radix sort: per-tile digit tables n / 4 (256 counters per 4096 pairs) + digit plane n (optional, from 2^26 pairs:
+    //     radix sort: per-tile digit tables n / 4 (256 counters per 4096 pairs) + digit plane n (optional, from 2^20 pairs:
     //                 ws_try_alloc -- the sort runs without it when it does not fit)                  = 1.25 n
     //     rerank:     one flag byte per slot n + tile aggregates n / 64 (L-first: + n / 128)          = 1.03 n
     //     pair chains: one verdict byte per record, at most n / 2
-    //     L-first:    the list of deep groups, 16 MiB
-    // = 69.4 n + 16 MiB; every allocation is rounded up to 256 bytes (about forty of them: < 16 KiB).  The DC arrays (10 n) and the inverse
+    //   and, for the whole of the L-first path (lfirst_path: held TOGETHER with the sort's and the rerank's temporaries above):
+    //     the list of deep groups 16 MiB, two giant lists with their arenas 5.6 MiB, the grid-wide measure's results 1 MiB = 23 MiB
+    //     (its arena of deep members, the depth tables and the next-break positions live in buffers of the 62.1 n that the path does not use otherwise)
+    // = 69.4 n + 23 MiB; every allocation is rounded up to 256 bytes (about forty of them: < 16 KiB).  The DC arrays (10 n) and the inverse
     // BWT's successor table (8 n) are allocated after the sort's temporaries are released and take their place.
-    // tests/test_gpu_parity.py::test_workspace_accounting checks peak <= size on contexts sized exactly to their block.
+    // tests/test_gpu_parity.py::test_workspace_accounting checks peak <= size on contexts sized exactly to their block, and
+    // tests/test_gpu_fullsize.py checks the n-proportional term where the constant is negligible (peak - 64 MiB <= 69.4 n at 1e8 bytes).
     const size_t sort_temporaries = 62 * max_n + max_n / 8, io = 6 * max_n, on_top = max_n / 4 + max_n;
     return sort_temporaries + io + on_top + max_n / 4 /* headroom */ + (64u << 20);
 }
@@ -178,6 +183,7 @@ int block_encode_common(dk_ctx *ctx, int model_id, const uint8_t *d_text, size_t
     DcStream s;
     s.n = n; s.init = fr.init; s.dist = fr.dist; s.sym = fr.sym; s.rank = fr.rank; s.run_end = fr.run_end; s.m = fr.m; s.origin = fr.origin;
     s.ready = fr.ready;
+    dk::set_preferred_numa(ctx->numa_node);
     int rc = encode_block_stream(model_id, s, out, out_cap, out_len);
     double ms_wait = 0.0;
     if (fr.ready) {  // (a coder that gave up early must not leave copies and host functions of this call behind)
@@ -190,6 +196,8 @@ int block_encode_common(dk_ctx *ctx, int model_id, const uint8_t *d_text, size_t
     ctx->stats.ms_entropy = t.ms() - ms_wait;
     ctx->stats.entropy_threads = static_cast<uint32_t>(dk::last_entropy_threads());
     ctx->stats.entropy_l3_group = dk::last_entropy_group();
+    ctx->stats.entropy_l3_numa = static_cast<int16_t>(dk::last_entropy_group_numa());
+    ctx->stats.gpu_numa = static_cast<int16_t>(ctx->numa_node);
     if (rc == DK_E_CAPACITY) return ctx->fail(rc, "output buffer of %zu bytes is too small", out_cap);
     if (rc) return ctx->fail(rc, "entropy stage failed (%d)", rc);
     return DK_OK;
@@ -243,6 +251,18 @@ int dk_ctx_create(int hip_device, size_t max_n, dk_ctx **out) {
     c->device = hip_device;
     c->max_n = max_n;
     bool ok = hipSetDevice(hip_device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    {   // the GPU's memory node: the host coder claims its last-level-cache group there first (entropy.cpp: l3_claim_order)
+        char bdf[32] = {0};
+        if (ok && hipDeviceGetPCIBusId(bdf, sizeof bdf, hip_device) == hipSuccess) {
+            for (char *q = bdf; *q; ++q) *q = static_cast<char>(std::tolower(static_cast<unsigned char>(*q)));
+            const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node";
+            if (FILE *f = std::fopen(path.c_str(), "r")) {
+                int node = -1;
+                if (std::fscanf(f, "%d", &node) == 1) c->numa_node = node;
+                std::fclose(f);
+            }
+        }
+    }
     c->ws_size = workspace_bytes(max_n);
     ok = ok && hipMalloc(reinterpret_cast<void **>(&c->ws), c->ws_size) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void **>(&c->d_mail), 1024 * sizeof(uint32_t)) == hipSuccess;
@@ -923,6 +943,13 @@ const char *dk_kernel_name(int slot) { return kernel_slot_name(slot); }
 // ---- host coding threads ------------------------------------------------------------------------------------------------------
 int dk_set_entropy_threads(int mode) { return set_entropy_thread_mode(mode); }
 int dk_host_l3_groups(int min_cores) { return host_l3_groups(min_cores); }
+int dk_dbg_l3_claim_order(const int *group_numa, int ngroups, int own, int preferred_numa, int *order_out) {
+    if (!group_numa || !order_out || ngroups <= 0 || own < 0 || own >= ngroups) return DK_E_ARG;
+    const std::vector<size_t> order = l3_claim_order(std::vector<int>(group_numa, group_numa + ngroups), static_cast<size_t>(own), preferred_numa);
+    for (size_t i = 0; i < order.size(); ++i) order_out[i] = static_cast<int>(order[i]);
+    return static_cast<int>(order.size());
+}
+void dk_set_entropy_numa_node(int node) { dk::set_preferred_numa(node); }
 void dk_last_entropy_info(int *threads, int *l3_group) {
     if (threads) *threads = last_entropy_threads();
     if (l3_group) *l3_group = last_entropy_group();

@@ -36,7 +36,7 @@ enum KernelSlot : int {
     K_IBWT_WALK,
     K_IBWT_JUMP,
     K_IBWT_EMIT,
-    K_BUCKET_STORE,
+    K_RESERVED_18,         // (k_bucket_store until round 5: the slot keeps its number)
     K_BIG_CLASSIFY,    // k_big_reduce + k_big_spine + k_big_apply
     K_BIG_BACK,
     K_PREFIX_PROBE,
@@ -64,6 +64,7 @@ struct Timer {
 
 struct dk_ctx {
     int device = -1;
+    int numa_node = -1;  // memory node the GPU hangs on (/sys/bus/pci/devices/<bdf>/numa_node; -1: unknown): where the host coder looks for its L3 group first
     size_t max_n = 0;
     hipStream_t stream = nullptr;
     // device workspace: one allocation, bump-allocated per API call (all stages of a call run in sequence)
@@ -174,15 +175,15 @@ int sort_pairs(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt, uint32_t *&val
 int sort_groups(dk_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, const uint32_t *starts, size_t ngroups, size_t npairs,
                 uint32_t above, int begin_bit, int end_bit);
 int local_sort_tiles(dk_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, size_t count, int begin_bit, int end_bit);  // experiment hook
-// scratch_b (n u64, may be null): second pair buffer of the LDS-window form (inverse of a permutation of up to 2^27 entries)
-// marked_val (may be null; only honoured by the LDS-window form, see inverse_through_windows): entries of idx with bit 31 set stand for
-// idx & 0x7FFFFFFF and take their value from marked_val[i] instead of i
-int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, size_t count, size_t limit, uint64_t *scratch,
-                         uint64_t *scratch_b, uint32_t *dst, const uint32_t *marked_val = nullptr);
+// rank[sa[p]] = p for a permutation sa of 0 .. n-1, through LDS windows (radix_sort.hip); scratch_a / scratch_b: n u64 each.
+// marked_val (may be null): entries of sa with bit 31 set stand for sa[p] & 0x7FFFFFFF and take their value from marked_val[p] instead of p
+int inverse_permutation(dk_ctx *ctx, const uint32_t *sa, size_t n, uint64_t *scratch_a, uint64_t *scratch_b, uint32_t *rank, const uint32_t *marked_val = nullptr);
 bool inverse_through_windows(size_t n);  // does the inverse of a permutation of n entries take the LDS-window form?
 // suffix_array.hip: d_sa_out may alias nothing in the workspace; d_text is caller or ctx owned
-// d_bwt / d_origin / bwt_written (all three or none): when the sort finds the BWT on its way (short-prefix path) it writes L and the
-// origin word and sets *bwt_written; otherwise the caller gathers (bwt_forward_device does both)
+// d_bwt / d_origin / bwt_written (all three or none): a caller that wants L.  The sort carries the symbol in front of every suffix along and
+// writes L and the origin word itself; it then sets *bwt_written -- and d_sa_out is SCRATCH WITH UNDEFINED CONTENTS on return (the L-first path
+// never completes a suffix array; on the rank path nobody writes SA entries once the ranks exist, and a period round keeps its next-break
+// positions there).  Only when *bwt_written comes back false does d_sa_out hold the suffix array (the caller gathers L: bwt_forward_device).
 int suffix_array_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_sa_out, uint8_t *d_bwt = nullptr,
                         uint32_t *d_origin = nullptr, bool *bwt_written = nullptr);
 int bwt_forward_device(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_sa, uint8_t *d_bwt, uint32_t *origin);

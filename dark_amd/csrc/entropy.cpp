@@ -805,7 +805,7 @@ std::vector<int> read_cpu_list(const std::string &path) {
     return out;
 }
 // The machine's last-level-cache groups (one per CCX on EPYC), read once from sysfs.
-struct L3Group { int id; cpu_set_t cpus; cpu_set_t primary; };  // primary: one hardware thread (the lowest numbered) of every core
+struct L3Group { int id; cpu_set_t cpus; cpu_set_t primary; int numa; };  // primary: one hardware thread (the lowest numbered) of every core; numa: its memory node (-1: unknown)
 struct Topology { std::vector<L3Group> groups; size_t threads_per_core = 1; };
 const Topology &topology() {
     static const Topology topo = [] {
@@ -822,6 +822,7 @@ const Topology &topology() {
             if (t.groups.empty()) t.threads_per_core = std::max<size_t>(1, read_cpu_list(base + "/topology/thread_siblings_list").size());
             L3Group g;
             g.id = l3.front();
+            g.numa = -1;
             CPU_ZERO(&g.cpus);
             CPU_ZERO(&g.primary);
             for (int c : l3) {
@@ -832,6 +833,13 @@ const Topology &topology() {
                 if (sib.empty() || *std::min_element(sib.begin(), sib.end()) == c) CPU_SET(c, &g.primary);
             }
             t.groups.push_back(g);
+        }
+        for (int node = 0, missing = 0; node < 1024 && missing < 8; ++node) {  // the memory node of every group (node numbers can have holes)
+            const std::vector<int> cpus = read_cpu_list("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
+            if (cpus.empty()) { ++missing; continue; }
+            missing = 0;
+            for (L3Group &g : t.groups)
+                if (std::find(cpus.begin(), cpus.end(), g.id) != cpus.end()) g.numa = node;
         }
         return t;
     }();
@@ -872,7 +880,8 @@ int open_group_lock(int group_id) {
 }
 #endif
 
-void note_group(int id);  // remembers the L3 group the calling thread's coding pass claimed (dk_last_entropy_info)
+void note_group(int id, int numa);  // remembers the L3 group the calling thread's coding pass claimed (dk_last_entropy_info)
+int preferred_numa();               // the memory node the calling thread's block comes from (its GPU's): groups there are tried first
 struct ThreadPair {
     int me = -1;
 #if defined(__linux__)
@@ -887,11 +896,11 @@ struct ThreadPair {
         for (size_t g = 0; g < topo.groups.size(); ++g)
             if (CPU_ISSET(cpu, &topo.groups[g].cpus)) own = g;
         if (own == topo.groups.size()) return false;
-        for (size_t step = 0; step < 2 * topo.groups.size(); ++step) {  // own, own+1, own-1, own+2, ...
-            const long off = (step & 1) ? static_cast<long>((step + 1) / 2) : -static_cast<long>(step / 2);
-            const long gi = static_cast<long>(own) + off;
-            if (gi < 0 || gi >= static_cast<long>(topo.groups.size()) || (step > 0 && off == 0)) continue;
-            const L3Group &g = topo.groups[static_cast<size_t>(gi)];
+        std::vector<int> numa_of(topo.groups.size());
+        for (size_t g = 0; g < topo.groups.size(); ++g) numa_of[g] = topo.groups[g].numa;
+        for (const size_t gidx : l3_claim_order(numa_of, own, preferred_numa())) {  // the GPU's memory node first, there and elsewhere by distance from the caller's group
+            const long gi = static_cast<long>(gidx);
+            const L3Group &g = topo.groups[gidx];
             // one hardware thread per core where the caller's mask allows it: two stages of one pipeline on the two hardware
             // threads of one core would share its execution units (seen as run-to-run swings of several percent)
             cpu_set_t usable;
@@ -911,7 +920,7 @@ struct ThreadPair {
             group = usable;
             lock_fd = fd;
             me = g.id;
-            note_group(me);
+            note_group(me, g.numa);
             return true;
         }
         return false;
@@ -1320,6 +1329,7 @@ struct DarkMergeSide5 {
     const uint64_t *inv;
     static inline UEvent mixed(const UEvent &a, const UEvent &b, const uint64_t *inv) {  // table::SumProxy::new(1, a, 2, b, 0) of the two halves
         const uint32_t total = (a.to & 0xFFFFu) + 2u * (b.to & 0xFFFFu), from = a.from + 2u * b.from, freq = (a.to >> 16) + 2u * (b.to >> 16);
+        static_assert(3u * kModelThreshold <= (1u << 14), "a + 2 b below the reciprocal table's 2^14 entries: the mask must never bite");
         return UEvent{inv[total & 0x3FFFu], from, from + freq};  // (totals stay below 3 * 2^12)
     }
     static inline UEvent mixed_bit(const UEvent &a, const UEvent &b, bool one) {
@@ -1331,12 +1341,12 @@ struct DarkMergeSide5 {
         const unsigned log = bit_length(dist + 1);
         const UEvent *a = half_a.next(), *b = half_b.next();
         if (!a || !b) return false;
-        e.raw(mixed(*a, *b, inv));
+        if (!e.raw(mixed(*a, *b, inv))) return false;
         for (unsigned i = 0; i + kMaxLogCode <= log; ++i) {
             a = half_a.next();
             b = half_b.next();
             if (!a || !b) return false;
-            e.raw(mixed_bit(*a, *b, i + kMaxLogCode < log));
+            if (!e.raw(mixed_bit(*a, *b, i + kMaxLogCode < log))) return false;
         }
         if (!DarkMergeSide::move(mantissa, e, DarkModel::modelled_mantissa_bits(dist))) return false;
         if (log > 4) DarkMergeSide::flat_tail(e, dist + 1, log);
@@ -1625,10 +1635,33 @@ int entropy_thread_mode() { return g_thread_mode.load(std::memory_order_relaxed)
 const uint64_t *reciprocal_table14() { return reciprocal_table(); }
 
 static thread_local int t_last_threads = 1;
-static thread_local int t_last_group = -1;
+static thread_local int t_last_group = -1, t_last_group_numa = -1, t_pref_numa = -1;
 int last_entropy_threads() { return t_last_threads; }
-namespace { void note_group(int id) { t_last_group = id; } }
+namespace { void note_group(int id, int numa) { t_last_group = id; t_last_group_numa = numa; } int preferred_numa() { return t_pref_numa; } }
 int last_entropy_group() { return t_last_threads > 1 ? t_last_group : -1; }
+int last_entropy_group_numa() { return t_last_threads > 1 ? t_last_group_numa : -1; }
+void set_preferred_numa(int node) { t_pref_numa = node; }
+// Order in which a coding pass tries to claim the machine's L3 groups (indices into the topology's list; numa[g] = memory node of group g, -1
+// unknown): the groups on the preferred node first -- the node the block's GPU hangs on: the pinned staging the coder reads was allocated by
+// the rank's first touch, next to that GPU, and with eight ranks on two sockets a group across the socket link reads all of it remotely -- and
+// within each class the caller's own group, then the others by distance (own + 1, own - 1, own + 2, ...).  preferred < 0, or no group there: by
+// distance alone.
+std::vector<size_t> l3_claim_order(const std::vector<int> &numa, size_t own, int preferred) {
+    std::vector<size_t> by_distance;
+    const size_t count = numa.size();
+    if (own >= count) return by_distance;
+    for (size_t step = 0; step < 2 * count; ++step) {
+        const long off = (step & 1) ? static_cast<long>((step + 1) / 2) : -static_cast<long>(step / 2);
+        const long gi = static_cast<long>(own) + off;
+        if (gi < 0 || gi >= static_cast<long>(count) || (step > 0 && off == 0)) continue;
+        by_distance.push_back(static_cast<size_t>(gi));
+    }
+    if (preferred < 0) return by_distance;
+    std::vector<size_t> order;
+    for (const size_t g : by_distance) if (numa[g] == preferred) order.push_back(g);
+    for (const size_t g : by_distance) if (numa[g] != preferred) order.push_back(g);
+    return order;
+}
 int set_entropy_thread_mode(int mode) {
     if (mode != 0 && mode != 1 && mode != 2 && mode != 4 && mode != 5) return DK_E_ARG;
     g_thread_mode.store(mode, std::memory_order_relaxed);

@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 #include <cstring>
 #include <memory>
 #if defined(__SSE4_1__)
@@ -499,6 +500,9 @@ constexpr size_t DC_STREAM_POISON = ~static_cast<size_t>(0);  // *ready: the pro
 int encode_block_stream(int model_id, const DcStream &s, uint8_t *out, size_t cap, size_t *out_len, int host_threads = 0);
 int last_entropy_threads();  // threads the calling thread's last encode_block_stream used
 int last_entropy_group();    // and the last-level-cache group (lowest cpu number in it) that pass claimed; -1: none (one thread)
+int last_entropy_group_numa();  // ... and that group's memory node (-1: none claimed / unknown)
+void set_preferred_numa(int node);  // calling thread: the memory node its next coding passes should claim their L3 group on (-1: no preference)
+std::vector<size_t> l3_claim_order(const std::vector<int> &numa, size_t own, int preferred);  // (entropy.cpp: the order groups are tried in)
 int set_entropy_thread_mode(int mode);  // 0 automatic | 1 | 2 | 4, process-wide (overrides DK_ENTROPY_THREADS)
 int host_l3_groups(int min_cores);      // L3 groups with at least min_cores cores usable by the calling thread
 // src/block/dc.rs:121-151: header, dc::decode pulling model.decode, origin.  *single = 1 when the block has a

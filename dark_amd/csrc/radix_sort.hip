@@ -788,30 +788,10 @@ int local_sort_tiles(dk_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, size_t cou
     return DK_OK;
 }
 
-// ---- bucketed scatter: dst[idx[i]] = val[i] for a huge, random idx ---------------------------------------------------
-// A random 4-byte store costs a whole 64-byte line at the HBM (read-modify-write).  Partition the (idx, val) pairs by the
-// top 8 bits of idx first (one stable radix pass over pairs, 16 B/pair), then store bucket by bucket: a bucket's
-// destinations span n/256 words (1.5 MiB at n = 1e8), the XCD-aware tile order keeps one bucket on one XCD, and its lines
-// are completed in that XCD's L2 before they are written back.
-__global__ __launch_bounds__(RS_BLOCK) void k_bucket_store(const uint64_t *__restrict__ pairs, size_t n, uint32_t ntiles,
-                                                            uint32_t *__restrict__ dst) {
-    const uint32_t per = gridDim.x / 8;
-    const uint32_t tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
-    if (tile >= ntiles) return;
-    const size_t base = static_cast<size_t>(tile) * RS_TILE;
-#pragma unroll
-    for (int k = 0; k < RS_KPT; ++k) {
-        const size_t i = base + static_cast<size_t>(k) * RS_BLOCK + threadIdx.x;
-        if (i < n) {
-            const uint64_t p = __builtin_nontemporal_load(pairs + i);  // streamed once: keep it out of the way of the destination lines
-            dst[static_cast<uint32_t>(p >> 32)] = static_cast<uint32_t>(p);
-        }
-    }
-}
-
 // ---- inverse permutation through LDS windows: rank[sa[p]] = p for a permutation sa of 0..n-1, n <= 2^27 ------------------------------
-// The bucketed store above leans on the L2 to complete the destination lines of a 1.5 MiB window before it writes them back; the
-// counters say it does not (round 2, 1e8: WRITE_SIZE 2.27 GB for 0.40 GB of rank stores).  Here the destination is cut into windows of
+// (Rounds 1-3 partitioned the pairs by the top byte of the suffix and stored bucket by bucket, leaning on the L2 to complete the destination
+// lines of a 1.5 MiB window before writing them back; the counters said it did not -- round 2, 1e8: WRITE_SIZE 2.27 GB for 0.40 GB of rank
+// stores.  Removed in round 5: every block size goes through the windows.)  The destination is cut into windows of
 // W = 2^wbits <= 2^15 words that fit the LDS, and every word leaves for HBM exactly once, in a full coalesced line:
 //   k_isa_split<true>   pairs (sa[p], p) into at most 64 SECTIONS of 64 windows each
 //   k_isa_split<false>  every section into its windows
@@ -975,52 +955,13 @@ static int inverse_permutation_windows(dk_ctx *ctx, const uint32_t *sa, size_t n
     return DK_OK;
 }
 
-// dst[idx[i]] = val[i] (val == nullptr: = i), i < count; idx values are distinct and < limit.  `scratch` holds count u64.
-// val == nullptr with count == limit is the inverse of a permutation: up to 2^27 entries it goes through LDS windows.
-bool inverse_through_windows(size_t n) { return n <= ISA_MAX_N; }
+// rank[sa[p]] = p (or marked_val[p] for entries of sa with bit 31 set) for a permutation sa of 0 .. n-1; scratch_a / scratch_b hold n u64 each
+bool inverse_through_windows(size_t n) { return n <= ISA_MAX_N; }  // (every block: n < 2^31)
 
-int scatter_u32_bucketed(dk_ctx *ctx, const uint32_t *idx, const uint32_t *val, size_t count, size_t limit, uint64_t *scratch,
-                         uint64_t *scratch_b, uint32_t *dst, const uint32_t *marked_val) {
-    if (count == 0) return DK_OK;
-    if (!val && count == limit && inverse_through_windows(count) && scratch_b)
-        return inverse_permutation_windows(ctx, idx, count, scratch, scratch_b, dst, marked_val);
-    if (marked_val) return ctx->fail(DK_E_INTERNAL, "scatter_u32_bucketed: marked values only in the LDS-window form");
-    const ChunkPlan cp = plan_chunks(count);
-    const size_t ntiles = cp.ntiles;
-    const size_t mark = ctx->ws_mark();
-    uint32_t *tile_pre = ctx->ws_alloc<uint32_t>(ntiles * 256);
-    uint32_t *chunk_sum = ctx->ws_alloc<uint32_t>(static_cast<size_t>(cp.nchunks) * 256);
-    uint32_t *digit_total = ctx->ws_alloc<uint32_t>(256);
-    if (!tile_pre || !chunk_sum || !digit_total) return DK_E_NOMEM;
-    hipStream_t st = ctx->stream;
-    DK_HIP(ctx, hipMemsetAsync(digit_total, 0, 256 * sizeof(uint32_t), st));
-    const unsigned lb = ceil_log2_u64(limit);
-    const int shift = 32 + static_cast<int>(lb > 8 ? lb - 8 : 0);
-    const size_t grid = 8 * div_up(ntiles, 8);
-    {
-        LaunchScope ls(ctx, K_RADIX_HIST, 8.0 * count);
-        k_radix_hist<HS_PAIRS><<<dim3(cp.nchunks), dim3(RS_BLOCK), 0, st>>>(nullptr, idx, val, nullptr, count, shift, cp.ntiles, cp.tiles_per_chunk, tile_pre, chunk_sum,
-                                                                          digit_total, TextKeys{});
-    }
-    {
-        LaunchScope ls(ctx, K_RADIX_SCAN, 2.0 * 1024.0 * cp.nchunks);
-        k_radix_scan<<<dim3(256), dim3(64), 0, st>>>(chunk_sum, cp.nchunks, digit_total);
-    }
-    {
-        LaunchScope ls(ctx, K_RADIX_SCATTER, 16.0 * count);
-        k_radix_scatter<true><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(nullptr, idx, val, scratch, nullptr, count, shift, TileOffsets{tile_pre, chunk_sum, cp.tiles_per_chunk},
-                                                                       static_cast<uint32_t>(ntiles), TextKeys{}, nullptr, SortFinalOut{});
-    }
-    {
-        LaunchScope ls(ctx, K_BUCKET_STORE, 12.0 * count);
-        // 72 KiB of (unused) dynamic LDS caps residency at 2 workgroups per CU: ~260 K pairs in flight per XCD, less than one
-        // bucket, so the lines of the bucket being written stay in that XCD's 4 MiB L2 until they are complete
-        const size_t lds_cap = static_cast<size_t>(DK_KNOB("DK_BUCKET_LDS", 72 * 1024));
-        k_bucket_store<<<dim3(grid), dim3(RS_BLOCK), lds_cap, st>>>(scratch, count, static_cast<uint32_t>(ntiles), dst);
-    }
-    DK_HIP(ctx, hipGetLastError());
-    ctx->ws_release(mark);
-    return DK_OK;
+int inverse_permutation(dk_ctx *ctx, const uint32_t *sa, size_t n, uint64_t *scratch_a, uint64_t *scratch_b, uint32_t *rank, const uint32_t *marked_val) {
+    if (n == 0) return DK_OK;
+    if (!inverse_through_windows(n) || !scratch_a || !scratch_b) return ctx->fail(DK_E_INTERNAL, "inverse_permutation: n = %zu", n);
+    return inverse_permutation_windows(ctx, sa, n, scratch_a, scratch_b, rank, marked_val);
 }
 
 }  // namespace dk

@@ -1936,13 +1936,13 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
         // it replaces 0.14 ms per 1e7 active ones)
         const bool marked = inverse_through_windows(n) && active * 4 > n;
         route |= marked ? DK_ROUTE_ISA_MARKED : 0u;
-        route |= inverse_through_windows(n) ? DK_ROUTE_ISA_WINDOWS : DK_ROUTE_ISA_BUCKETS;
+        route |= DK_ROUTE_ISA_WINDOWS;
         uint32_t *head_pos = marked ? pos_alt : nullptr;
         {
             LaunchScope ls(ctx, K_PLACE_ACTIVE, (marked ? 28.0 : 12.0) * active);
             k_place_active<<<dim3(div_up(active, 256)), dim3(256), 0, st>>>(vals, pos, gid, gstart, active, d_sa, head_pos);
         }
-        DK_TRY(scatter_u32_bucketed(ctx, d_sa, nullptr, n, n, keys_alt, keys_3, rank, head_pos));  // rank[SA[p]] = p (keys_alt / keys_3: free between rounds)
+        DK_TRY(inverse_permutation(ctx, d_sa, n, keys_alt, keys_3, rank, head_pos));  // rank[SA[p]] = p (keys_alt / keys_3: free between rounds)
         if (!marked) {
             LaunchScope ls(ctx, K_PLACE_ACTIVE, 16.0 * active);
             k_rank_active<<<dim3(div_up(active, 256)), dim3(256), 0, st>>>(vals, pos, gid, gstart, active, rank);

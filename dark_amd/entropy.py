@@ -51,6 +51,18 @@ def last_info():
     return int(t.value), int(g.value)
 
 
+def claim_order(group_numa, own, preferred_numa):
+    """the order in which a coding pass tries the L3 groups of a machine described by the caller (group_numa[g] = memory node of group g): the
+    groups on preferred_numa first, within each class the caller's own group, then by distance (dk_dbg_l3_claim_order)"""
+    k = len(group_numa)
+    arr = (C.c_int * k)(*[int(x) for x in group_numa])
+    out = (C.c_int * k)()
+    got = _lib.load().dk_dbg_l3_claim_order(arr, k, int(own), int(preferred_numa), out)
+    if got < 0:
+        raise DarkError(got, "dk_dbg_l3_claim_order")
+    return [int(out[i]) for i in range(got)]
+
+
 def plan_threads(groups4, groups2, ranks, share, groups5=0):
     """The thread form every rank of a node should use so that none of them loses the race for an L3 group: groups5 / groups4 / groups2 = the
     SMALLEST number of groups with >= 5 / >= 4 / >= 2 usable cores any rank sees, ranks = ranks on the node, share = host CPUs per rank."""

@@ -197,7 +197,8 @@ typedef struct dk_stats {
     double kernel_ms[DK_NUM_KERNEL_SLOTS];
     double kernel_bytes[DK_NUM_KERNEL_SLOTS]; /* algorithmic bytes summed over launches */
     uint32_t sa_route;        /* DK_ROUTE_* bits: which ways through the suffix sort the last call took (tests assert the route they are named after) */
-    uint32_t reserved_;
+    int16_t entropy_l3_numa;  /* memory node of that group (-1: none claimed / unknown) ... */
+    int16_t gpu_numa;         /* ... and of the context's GPU (/sys/bus/pci/devices/<bdf>/numa_node; -1: unknown): the coder looks for its group there first */
     uint64_t ws_peak_bytes;   /* most the context's device workspace has held at once since dk_ctx_create ... */
     uint64_t ws_size_bytes;   /* ... and its size (about 69.4 x the capacity + 64 MiB) */
 } dk_stats;
@@ -206,7 +207,7 @@ typedef struct dk_stats {
 #define DK_ROUTE_TEXT_ROUND 0x4u        /* a text-extension round ran */
 #define DK_ROUTE_ISA_WINDOWS 0x8u       /* rank array through LDS windows */
 #define DK_ROUTE_ISA_MARKED 0x10u       /* ... with the active suffixes' head positions handed over by marked SA entries */
-#define DK_ROUTE_ISA_BUCKETS 0x20u      /* rank array by the bucketed store (blocks above 2^27 suffixes) */
+#define DK_ROUTE_ISA_BUCKETS 0x20u      /* reserved (rounds 1-4: rank array by a bucketed store for blocks above 2^27 suffixes; every block goes through the windows now) */
 #define DK_ROUTE_GENERAL_ROUND 0x40u    /* a doubling round in its general form ran */
 #define DK_ROUTE_BIG_GROUPS 0x80u       /* ... with groups of more than 1024 members through the global sort */
 #define DK_ROUTE_INPLACE_ROUNDS 0x100u  /* in-place (plateau) rounds ran */
@@ -232,8 +233,15 @@ const char *dk_kernel_name(int slot);
 int dk_set_entropy_threads(int mode);
 /* number of last-level-cache groups in which the calling thread may use at least min_cores cores */
 int dk_host_l3_groups(int min_cores);
-/* the calling thread's last host coding pass: threads used (1 / 2 / 4) and the L3 group claimed (-1: none).  Either may be NULL. */
+/* the calling thread's last host coding pass: threads used (1 / 2 / 4 / 5) and the L3 group claimed (-1: none).  Either may be NULL. */
 void dk_last_entropy_info(int *threads, int *l3_group);
+/* memory node the calling thread's coding passes should claim their L3 group on first (-1: none; the block entry points set it to their
+ * context's GPU's node themselves -- for callers of dk_stream_encode that know where their staging memory lives) */
+void dk_set_entropy_numa_node(int node);
+/* the order in which a coding pass tries the machine's L3 groups, on a topology given by the caller (group_numa[g] = memory node of group g,
+ * own = the caller's group, preferred_numa as above): indices into order_out[ngroups], returns how many.  For tests of the policy on
+ * machines the test host is not (two sockets, eight GPUs). */
+int dk_dbg_l3_claim_order(const int *group_numa, int ngroups, int own, int preferred_numa, int *order_out);
 
 /* ---- stage-level debug entry points used by the parity tests ------------------------------------------------ */
 /* dk_stream_encode on a distance stream that is still ARRIVING, the way dk_dev_block_encode feeds its host coder while the D2H copies

@@ -75,13 +75,13 @@ def test_two_rank_block_parallel_gather():
     assert len(by["rank0"][2]) == 2 and by["rank0"][2][1] == by["rank1"][2][0]
 
 
-def _run_bench(cmd):
+def _run_bench(cmd, timeout=280):
     import json
     import subprocess
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout  # rank 0 prints ONE JSON line
@@ -95,6 +95,33 @@ def test_bench_launcher_starts_n_ranks():
     res = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--stub-exchange"])
     assert res["n_gpus"] == 2 and res["gathered_streams_decode"] is True and len(res["stream_bytes"]) == 2
     _check_rank_reports(res, 2)
+
+
+@pytest.mark.timeout(600)
+def test_eight_ranks_stub_exchange():
+    """the 8-rank shape of the node the driver measures on -- launcher, process group, the thread plan over eight reports, the
+    padded gather of eight streams of eight different lengths -- rehearsed with backend gloo (no GPU; eight processes on this host's cores)."""
+    res = _run_bench([sys.executable, "bench.py", "--gpus", "8", "--steps", "1", "--warmup", "0", "--stub-exchange", "--node-gpus", "8"], timeout=560)
+    assert res["n_gpus"] == 8 and res["gathered_streams_decode"] is True
+    assert len(res["stream_bytes"]) == 8 and len(set(res["stream_bytes"])) == 8  # eight lengths, every one padded to the longest on the way
+    _check_rank_reports(res, 8)
+    assert all("l3_group_numa" in r and "gpu_numa" in r for r in res["ranks"])
+
+
+def test_l3_groups_are_claimed_on_the_gpus_memory_node_first():
+    """two sockets with eight L3 groups each (2 x EPYC 9575F: what an 8 x MI355X node looks like), four GPUs per socket.  A rank
+    whose GPU hangs on node 1 tries the groups of node 1 first -- nearest to where it runs -- and only then the other socket's; without a
+    preference (or on a one-node host) the order is by distance alone, as before."""
+    from dark_amd import entropy
+    numa = [0] * 8 + [1] * 8
+    assert entropy.claim_order(numa, 2, 1) == [8, 9, 10, 11, 12, 13, 14, 15, 2, 3, 1, 4, 0, 5, 6, 7]
+    assert entropy.claim_order(numa, 10, 1) == [10, 11, 9, 12, 8, 13, 14, 15, 7, 6, 5, 4, 3, 2, 1, 0]
+    assert entropy.claim_order(numa, 10, 0) == [7, 6, 5, 4, 3, 2, 1, 0, 10, 11, 9, 12, 8, 13, 14, 15]
+    assert entropy.claim_order(numa, 2, -1) == [2, 3, 1, 4, 0, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]
+    assert entropy.claim_order([-1] * 4, 1, 0) == [1, 2, 0, 3]          # no node information: by distance
+    assert entropy.claim_order([0, 0, 0], 0, 5) == [0, 1, 2]             # a node without any group: by distance
+    with pytest.raises(Exception):
+        entropy.claim_order(numa, 16, 0)
 
 
 def _check_rank_reports(res, world):

@@ -86,6 +86,18 @@ def test_multi_gpu_entry_point(orc):
         dark_amd.multi_block_encode("dark", blocks, devices=[0, 99])
 
 
+def test_multi_gpu_entry_point_with_eight_device_slots(orc):
+    """the 8-GPU form of the call -- eight device slots, eight contexts, eight host threads inside one dk_multi_block_encode --
+    on the one GPU the box has (every slot is GPU 0), sixteen blocks of different sizes so that every slot takes two: block i -> devices[i mod 8]."""
+    blocks = [datagen.wiki_like(120_000 + 5003 * i, 80 + i) for i in range(15)] + [np.full(2000, 65, np.uint8)]
+    streams = dark_amd.multi_block_encode("dark", blocks, devices=[0] * 8, host_threads_per_gpu=1)
+    assert len(streams) == 16
+    for b, s in zip(blocks, streams):
+        assert s == orc.block_dc_encode("dark", b)
+    back = dark_amd.multi_block_decode("dark", streams, [len(b) for b in blocks], devices=[0] * 8, host_threads_per_gpu=1)
+    assert back == [b.tobytes() for b in blocks]
+
+
 @pytest.mark.skipif(not os.environ.get("DARK_CORPUS_DIR"), reason="set DARK_CORPUS_DIR to a directory holding book1 and/or enwik8")
 def test_real_corpus_sizes():
     """README.md:20: book1 -> 214 445 B with the `dark` model (file = 4-byte header of src/main.rs:102 + stream).  The only pin the

@@ -146,6 +146,11 @@ def test_fullsize_stream_equals_oracle(orc, workload):
                 d_out = torch.empty(n, dtype=torch.uint8, device="cuda")
                 ctx.dev_block_decode("dark", stream, n, d_out)
                 assert torch.equal(d_out, d_in)
+        # the n-proportional term of the workspace where the 64 MiB constant is negligible (csrc/abi.cpp workspace_bytes: 69.4 n + 23 MiB; the
+        # context was sized for exactly this block and has been through the suffix-array path, the L-first path with its big rounds, deep and token
+        # routes -- whichever the block takes -- DC, encode and decode)
+        ws = ctx.stats()
+        assert ws["ws_peak_bytes"] <= ws["ws_size_bytes"] and ws["ws_peak_bytes"] - (64 << 20) <= 69.4 * n, (ws["ws_peak_bytes"], ws["ws_size_bytes"], n)
         print(workload, "rounds", st["rounds"], "sort passes", st["sort_passes"], "sa ms", round(st["ms_sa"], 2), "oracle seconds",
               {k: round(v, 1) for k, v in job["seconds"].items()})
     oracle_jobs.drop(workload)
