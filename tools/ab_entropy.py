@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--workload", default="enwik8_like_1e8")
+    ap.add_argument("--decode", action="store_true", help="time dk_dev_block_decode of the stream as well (ms_entropy of the decode = header + range decoder + model + rebuild of L)")
     ap.add_argument("libs", nargs="+")
     args = ap.parse_args()
     block = datagen.WORKLOADS[args.workload]()
@@ -45,7 +46,8 @@ def main():
         lib.dk_last_error.restype = ctypes.c_char_p
         lib.dk_last_error.argtypes = [ctypes.c_void_p]
         threads = int(opt.split("=")[1]) if opt.startswith("threads=") else None
-        libs.append(dict(name=name, lib=lib, threads=threads, wall=[], ent=[], dev=[], stream=None))
+        lib.dk_dev_block_decode.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p]
+        libs.append(dict(name=name, lib=lib, threads=threads, wall=[], ent=[], dev=[], stream=None, dwall=[], dent=[]))
     stats = (ctypes.c_double * 1024)()
     for rnd in range(args.rounds):
         for L in libs:
@@ -69,6 +71,19 @@ def main():
             s = out[:ln.value].tobytes()
             assert L["stream"] in (None, s), "stream changed between turns"
             L["stream"] = s
+            if args.decode:
+                d_out = torch.empty(n, dtype=torch.uint8, device="cuda")
+                for step in range(3):
+                    t0 = time.perf_counter()
+                    rc = lib.dk_dev_block_decode(ctx, 0, out.ctypes.data, ln.value, n, d_out.data_ptr())
+                    dt = 1e3 * (time.perf_counter() - t0)
+                    assert rc == 0, (L["name"], rc, lib.dk_last_error(ctx))
+                    lib.dk_get_stats(ctx, stats)
+                    if step:
+                        L["dwall"].append(dt)
+                        L["dent"].append(stats[5])
+                assert torch.equal(d_out, d_in), "decode does not give the block back"
+                del d_out
             lib.dk_ctx_destroy(ctx)
             print("round %d %-10s wall %s  ms_entropy %s" % (rnd, L["name"], " ".join("%.1f" % x for x in L["wall"][-args.steps:]),
                                                               " ".join("%.1f" % x for x in L["ent"][-args.steps:])), flush=True)
@@ -78,6 +93,9 @@ def main():
                                   "ms_entropy_median": round(float(np.median(L["ent"])), 2), "ms_entropy_min": round(float(np.min(L["ent"])), 2),
                                   "ms_device_median": round(float(np.median(L["dev"])), 2),
                                   "stream_bytes": len(L["stream"]), "stream_equals_first": L["stream"] == libs[0]["stream"]}
+        if L["dwall"]:
+            res["libs"][L["name"]].update({"decode_wall_ms_median": round(float(np.median(L["dwall"])), 2), "decode_ms_entropy_median": round(float(np.median(L["dent"])), 2),
+                                           "decode_MBps": round(n / float(np.median(L["dwall"])) / 1e3, 2)})
     print(json.dumps(res))
 
 
