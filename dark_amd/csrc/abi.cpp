@@ -269,6 +269,8 @@ int dk_ctx_create(int hip_device, size_t max_n, dk_ctx **out) {
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&c->h_mail), 1024 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMemset(c->d_mail, 0, 1024 * sizeof(uint32_t)) == hipSuccess;
     for (hipEvent_t &e : c->round_ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         dk_ctx_destroy(c);
         return DK_E_NOMEM;
@@ -286,6 +288,9 @@ void dk_ctx_destroy(dk_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->round_ev) if (e) (void)hipEventDestroy(e);
+    if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ws) (void)hipFree(c->ws);
     if (c->d_mail) (void)hipFree(c->d_mail);
     if (c->h_mail) (void)hipHostFree(c->h_mail);

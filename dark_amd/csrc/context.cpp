@@ -58,7 +58,8 @@ void *dk_ctx::ws_alloc_bytes(size_t bytes) {
     return p;
 }
 
-void dk_ctx::prof_begin(int slot, double bytes) {
+void dk_ctx::prof_begin(int slot, double bytes, hipStream_t on) {
+    if (!on) on = stream;
     if (ev_next + 2 > ev_pool.size()) {
         for (int i = 0; i < 64; ++i) {
             hipEvent_t e;
@@ -66,20 +67,21 @@ void dk_ctx::prof_begin(int slot, double bytes) {
             ev_pool.push_back(e);
         }
     }
-    Pending p{slot, ev_pool[ev_next], ev_pool[ev_next + 1], bytes};
+    Pending p{slot, ev_pool[ev_next], ev_pool[ev_next + 1], bytes, on};
     ev_next += 2;
-    (void)hipEventRecord(p.a, stream);
+    (void)hipEventRecord(p.a, on);
     ev_pending.push_back(p);
 }
 
 void dk_ctx::prof_end() {
     if (ev_pending.empty()) return;
-    (void)hipEventRecord(ev_pending.back().b, stream);
+    (void)hipEventRecord(ev_pending.back().b, ev_pending.back().on);
 }
 
 void dk_ctx::prof_collect() {
     if (ev_pending.empty()) return;
     (void)hipStreamSynchronize(stream);
+    if (side_stream) (void)hipStreamSynchronize(side_stream);
     const bool each = DK_KNOB("DK_TRACE_LAUNCHES", 0) != 0;  // (tuning build: every bracketed launch in order, for tools/kernel_breakdown.py)
     for (const Pending &p : ev_pending) {
         float ms = 0.f;

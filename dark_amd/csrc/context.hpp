@@ -67,6 +67,10 @@ struct dk_ctx {
     int numa_node = -1;  // memory node the GPU hangs on (/sys/bus/pci/devices/<bdf>/numa_node; -1: unknown): where the host coder looks for its L3 group first
     size_t max_n = 0;
     hipStream_t stream = nullptr;
+    // a second stream for work that needs nothing from what the main stream does meanwhile (the L-first path's deep groups, ordered beside the
+    // rounds that follow), forked from and joined to the main stream with the two events
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // device workspace: one allocation, bump-allocated per API call (all stages of a call run in sequence)
     char *ws = nullptr;
     size_t ws_size = 0, ws_used = 0, ws_peak = 0;
@@ -92,7 +96,7 @@ struct dk_ctx {
     bool profiling = false;
     hipEvent_t round_ev[8] = {};  // suffix sort: one per in-place round in flight (live count read back one round late)
     std::vector<hipEvent_t> ev_pool;
-    struct Pending { int slot; hipEvent_t a, b; double bytes; };
+    struct Pending { int slot; hipEvent_t a, b; double bytes; hipStream_t on; };
     std::vector<Pending> ev_pending;
     size_t ev_next = 0;
 
@@ -109,7 +113,7 @@ struct dk_ctx {
     void ws_release(size_t mark) { ws_used = mark; }
 
     // profiling: bracket a kernel launch with events on the context's stream
-    void prof_begin(int slot, double bytes);
+    void prof_begin(int slot, double bytes, hipStream_t on = nullptr);  // on: the stream the bracketed launches go to (default: `stream`)
     void prof_end();
     void prof_collect();  // after a stream sync: fold finished event pairs into stats
     int ensure_stage(size_t bytes);
@@ -132,7 +136,7 @@ namespace dk {
 // RAII kernel bracket: DK_LAUNCH(ctx, slot, bytes) { kernel<<<...>>>(...); }
 struct LaunchScope {
     dk_ctx *c;
-    LaunchScope(dk_ctx *ctx, int slot, double bytes) : c(ctx) { if (c->profiling) c->prof_begin(slot, bytes); }
+    LaunchScope(dk_ctx *ctx, int slot, double bytes, hipStream_t on = nullptr) : c(ctx) { if (c->profiling) c->prof_begin(slot, bytes, on); }
     ~LaunchScope() { if (c->profiling) c->prof_end(); }
 };
 

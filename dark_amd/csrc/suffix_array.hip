@@ -1721,10 +1721,10 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
         // (the arena of the deep groups: the second list buffers of the suffix-array path, which this path does not use, and the upper half of the
         //  initial keys' buffer -- the lower half holds the next-break positions of a token round)
         //  initial keys' buffer -- 8 n bytes: [0, 4 n) the next-break positions of a round with tokens, [4 n, 5 n) the arena's symbols, then the depth of every
-        //  group (n / 2 + 2 words) and of every big group (n / 32 + 2 words)
+        //  group (n / 2 + 2 words) and of every big group (n / 32 + 2 words), and a byte per big group (periodic or not)
         uint8_t *kb8 = reinterpret_cast<uint8_t *>(keys);
         uint32_t *gdepth = reinterpret_cast<uint32_t *>(kb8 + ((5 * n + 15) & ~size_t(15)));
-        const LfBuffers b{keys_alt, keys_3, vals_3, vals, rank, sym_alt, vals_alt, pos, gid, sym, gstart, bigidx, bigoff, pos_alt, gid_alt, kb8 + 4 * n, gdepth, gdepth + n / 2 + 2};
+        const LfBuffers b{keys_alt, keys_3, vals_3, vals, rank, sym_alt, vals_alt, pos, gid, sym, gstart, bigidx, bigoff, pos_alt, gid_alt, kb8 + 4 * n, gdepth, gdepth + n / 2 + 2, reinterpret_cast<uint8_t *>(gdepth + n / 2 + 2 + n / 32 + 2)};
         bool done = false, pristine = true;
         route |= DK_ROUTE_LFIRST;
         // (the initial keys are read by the first rerank only: their buffer holds the next-break positions of a token round later)
@@ -1860,7 +1860,7 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
         uint32_t *spare = reinterpret_cast<uint32_t *>(keys);
         // (the arena of the deep groups: the caller's own list, free once the first rerank has filtered it)
         uint32_t *gdepth = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(keys) + ((5 * n + 15) & ~size_t(15)));  // (behind the big list's symbols, see above)
-        const LfBuffers b{keys_alt, keys_3, vals_3, spare, rank, reinterpret_cast<uint8_t *>(spare + n), vals_alt, pos_alt, gid_alt, sym_alt, gstart, bigidx, bigoff, vals, pos, sym, gdepth, gdepth + n / 2 + 2};
+        const LfBuffers b{keys_alt, keys_3, vals_3, spare, rank, reinterpret_cast<uint8_t *>(spare + n), vals_alt, pos_alt, gid_alt, sym_alt, gstart, bigidx, bigoff, vals, pos, sym, gdepth, gdepth + n / 2 + 2, reinterpret_cast<uint8_t *>(gdepth + n / 2 + 2 + n / 32 + 2)};
         const LfFrom from{vals, pos, gid, sym, active};
         bool done = false, pristine = true;
         if (trace) fprintf(stderr, "[dk] %zu active, %zu of them in big groups, depth %llu: the L-first path takes over\n", active, nbig, (unsigned long long)h);
