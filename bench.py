@@ -599,6 +599,20 @@ def main():
                 continue
             if not corpus_path and cand.get("workload") == args.workload and (pmc is None or cand.get("round", 0) >= pmc.get("round", 0)):
                 pmc, pmc_path = cand, os.path.relpath(path, ROOT)
+        # a committed profile describes THIS code only if it saw the same launches: the profiled command's own count of bracketed launches per
+        # step and kernel slot (dk_stats, copied into the profile by tools/pmc_traffic.py --bench-line) must agree with this run's, else the
+        # profile is stale (taken on an earlier commit) and no traffic figure is derived from it
+        my_launches = {slot: round(v["launches"] / k, 3) for slot, v in kern.items()}
+        traffic_profile_stale = None
+        if pmc and not args.n:
+            theirs = pmc.get("scope_launches_per_step")
+            mism = {"(profile without launch counts)": []} if theirs is None else {
+                slot: [theirs.get(slot, 0.0), my_launches.get(slot, 0.0)] for slot in set(theirs) | set(my_launches)
+                if not slot.startswith(("k_dc_", "k_ibwt_")) and abs(theirs.get(slot, 0.0) - my_launches.get(slot, 0.0)) > 0.01}
+            traffic_profile_stale = bool(mism)
+            if mism:
+                print("bench.py: %s is stale -- launches per step [profile, this run] differ: %s" % (pmc_path, mism), file=sys.stderr)
+                pmc = None
         if dom_name:
             dk_ = kern[dom_name]
             achieved = dk_["bytes"] / (dk_["ms"] * 1e-3) / 1e9
@@ -665,7 +679,9 @@ def main():
             "host_entropy_threads": stats["entropy_threads"], "host_cpu_share_per_rank": share,
             **thread_summary(reports, thread_plan),
             "kernel_ms_per_step": {kk: round(v["ms"] / k, 3) for kk, v in sorted(kern.items(), key=lambda x: -x[1]["ms"])},
+            "kernel_launches_per_step": my_launches,
             "roofline": roofline,
+            "traffic_profile_stale": traffic_profile_stale,  # true: the newest committed PMC profile of this workload saw other launch counts -> traffic: null
             "bwt_forward_roofline": fwd_roofline,
             "pipelined": pipelined,
             "gather_ms": gather_ms,

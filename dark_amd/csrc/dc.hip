@@ -8,6 +8,15 @@
 // n - b - rank - 1 with rank = #{c : last_c(n) > b} (its place in the final MTF list).  One entry per run, in position
 // order, is exactly what EncodeIterator yields; Context.last_rank of the entry for run r is the rank found at r's start.
 //
+// THE KERNELS WALK THE BWT BACKWARDS (round 5).  Forwards, the distance of a run is known when its symbol comes BACK -- a 4-byte store into the slot of
+// an earlier run, scattered over the last thousand run slots on a wide alphabet: 2^30 random bytes wrote 22 GB for 6.4 GB of outputs.  The reversed
+// sequence R[p'] = L[n-1-p'] has the same runs, and the number of distinct symbols between two occurrences of s is the same from either side: walking
+// R, the run that STARTS at i' (ending at b = n-1-i' in L) finds its previous occurrence in R -- its NEXT one in L -- and the very same
+// i' - b' - rank - 1 now belongs to the run at hand: every chunk's distances leave as whole lines, at index m-1-(run index in R).  A symbol's
+// first occurrence in R is its last run in L, whose distance is the reference's final sweep, n - b - rank - 1 = i' - (distinct symbols before i'
+// in R): no sweep kernel.  init[s] = n - (last position of s in R + 1) comes from the final table.  Context.last_rank of a run (the rank found at
+// ITS start in L; only the rawdc dump reads it) is what the run before it in L order of its symbol computes: the one scattered (byte) store left.
+// Below, "position", "previous", "last occurrence" are meant in R.
 //   k_dc_summary   one wave per tile of 4096 positions: last position (+ run index) of every symbol inside the tile,
 //                  number of run starts in the tile
 //   k_dc_runscan   exclusive sum of the run counts                     (run index of every tile's first new run)
@@ -36,21 +45,27 @@ constexpr int DC_MARKS_TILE = 4;     // distinct symbols in a tile above which t
 constexpr int DC_MARKS_B = 6;        // first occurrences per chunk above which the bitmap route is taken (tiles that keep the bitmap)
 constexpr int DC_FEW_LATER = 16;     // wide tiles: lanes per chunk that are neither the first nor the second of their symbol up to which each finds its predecessor by itself
 
-// Stage one tile into wave-private LDS: s[PAD + j] = L[base + j]; with PAD > 0 also its neighbours L[base-1] and L[base+DC_TILE].
+// R[p] = L[n-1-p]
+__device__ __forceinline__ uint32_t rev_at(const uint8_t *__restrict__ L, size_t n, size_t p) { return L[n - 1 - p]; }
+// Stage one tile OF THE REVERSED SEQUENCE into wave-private LDS: s[PAD + j] = R[base + j]; with PAD > 0 also its neighbours R[base-1] and
+// R[base+DC_TILE].  Sixteen consecutive bytes of R are sixteen bytes of L read backwards: two unaligned 8-byte loads, byte-swapped.
 template <int PAD>
 __device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ L, size_t n, size_t base, uint8_t *s, int lane) {
-    const bool aligned = (reinterpret_cast<uintptr_t>(L) & 15) == 0;
+    typedef uint64_t __attribute__((aligned(1))) unaligned_u64;
+    typedef const unaligned_u64 __attribute__((address_space(1))) *gptr8;
     for (int j = lane * 16; j < DC_TILE; j += 64 * 16) {
         const size_t p = base + j;
-        if (aligned && p + 16 <= n) {
-            *reinterpret_cast<uint4 *>(s + PAD + j) = *reinterpret_cast<const uint4 *>(L + p);
+        if (p + 16 <= n) {
+            const size_t lo = n - 16 - p;  // L[lo .. lo + 16) = R[p + 15 .. p] backwards
+            const uint64_t w0 = __builtin_bswap64(*(gptr8)(L + lo + 8)), w1 = __builtin_bswap64(*(gptr8)(L + lo));  // R[p .. p+8), R[p+8 .. p+16)
+            *reinterpret_cast<uint4 *>(s + PAD + j) = make_uint4(static_cast<uint32_t>(w0), static_cast<uint32_t>(w0 >> 32), static_cast<uint32_t>(w1), static_cast<uint32_t>(w1 >> 32));
         } else {
-            for (int b = 0; b < 16; ++b) s[PAD + j + b] = (p + b < n) ? L[p + b] : 0;
+            for (int b = 0; b < 16; ++b) s[PAD + j + b] = (p + b < n) ? static_cast<uint8_t>(rev_at(L, n, p + b)) : 0;
         }
     }
     if (PAD > 0 && lane == 0) {
-        s[PAD - 1] = base > 0 ? L[base - 1] : 0;
-        s[PAD + DC_TILE] = (base + DC_TILE < n) ? L[base + DC_TILE] : 0;
+        s[PAD - 1] = base > 0 ? static_cast<uint8_t>(rev_at(L, n, base - 1)) : 0;
+        s[PAD + DC_TILE] = (base + DC_TILE < n) ? static_cast<uint8_t>(rev_at(L, n, base + DC_TILE)) : 0;
     }
 }
 
@@ -249,7 +264,7 @@ __device__ __forceinline__ uint32_t write_lane(uint32_t value, int sel, uint32_t
 // that do not occur in the tile count as well: those lanes add what the 256-entry table of the tile's start says.
 // About 70 vector instructions per chunk instead of 270.
 struct FewOut {
-    uint32_t *dist; uint8_t *sym; uint8_t *rank; uint32_t *run_end; uint32_t *init; uint32_t *final_last; uint32_t *final_lrun;
+    uint32_t *dist; uint8_t *sym; uint8_t *rank; uint32_t *run_end; uint32_t *final_last; uint32_t *final_lrun; uint32_t m;  // m: runs of the block
 };
 __device__ __forceinline__ void dc_tile_few(const uint8_t *s, uint32_t before_tile, size_t n, size_t base, int lane, uint32_t nsym, uint32_t set4,
                                             const uint2 *pr, uint32_t r, bool last_tile, const FewOut &o) {
@@ -294,11 +309,11 @@ __device__ __forceinline__ void dc_tile_few(const uint8_t *s, uint32_t before_ti
                 if (q == kq) prevlane = pl;
             }
             const uint32_t b1 = kq == 0 ? lp1[0] : kq == 1 ? lp1[1] : kq == 2 ? lp1[2] : lp1[3];
-            uint32_t cnt = 0;  // (0 for a symbol's first occurrence in the block: there is no previous occurrence to count from)
+            uint32_t cnt = 0;  // (a symbol's first occurrence, b1 = 0: every symbol seen so far counts -- the final sweep's rank)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) cnt += (b1 != 0 && q != kq && lp1[q] > b1) ? 1u : 0u;
+            for (int q = 0; q < 4; ++q) cnt += (q != kq && lp1[q] > b1) ? 1u : 0u;
             // first run start of a symbol inside the tile: its previous occurrence (if any) lies in front of the tile
-            uint64_t slow = __ballot(start && b1 != 0 && b1 <= base32);
+            uint64_t slow = __ballot(start && b1 <= base32);
             while (slow) {
                 const int bit = __builtin_ctzll(slow);
                 slow &= slow - 1;
@@ -312,13 +327,12 @@ __device__ __forceinline__ void dc_tile_few(const uint8_t *s, uint32_t before_ti
             const uint32_t prun_in = static_cast<uint32_t>(__shfl(static_cast<int>(run1), prevlane >= 0 ? prevlane : lane, 64));
             if (start) {
                 const uint32_t i = base32 + static_cast<uint32_t>(j);
-                const uint32_t ridx = r + starts_before;
-                (o.sym + r)[starts_before] = static_cast<uint8_t>(c);
-                if (o.rank) (o.rank + r)[starts_before] = static_cast<uint8_t>(cnt);
+                const uint32_t at = o.m - 1u - (r + starts_before);  // this run's index in L order
+                o.sym[at] = static_cast<uint8_t>(c);
+                o.dist[at] = i - b1 - cnt;  // = i - b - rank - 1; a first occurrence (b1 = 0): i - rank, the final sweep's n - b - rank - 1
                 const uint32_t prun1 = prevlane >= 0 ? prun_in : (kq == 0 ? crun[0] : kq == 1 ? crun[1] : kq == 2 ? crun[2] : crun[3]);
-                if (b1) o.dist[prun1 - 1u] = i - b1 - cnt;  // = i - b - rank - 1
-                else o.init[c] = i;                         // first occurrence in the block
-                if (o.run_end && ridx > 0) o.run_end[ridx - 1] = i - 1;
+                if (o.rank && b1) o.rank[o.m - prun1] = static_cast<uint8_t>(cnt);  // the rank found at the start of this symbol's next run in L
+                if (o.run_end) o.run_end[at] = static_cast<uint32_t>(n - 1) - i;    // where the run ends in L
             }
         }
         // carries: the last lane of every symbol of this chunk (a chunk without a run start continues the open run: same rule)
@@ -332,8 +346,7 @@ __device__ __forceinline__ void dc_tile_few(const uint8_t *s, uint32_t before_ti
         }
         r += static_cast<uint32_t>(__popcll(S));
     }
-    if (last_tile) {  // publish the final table for the sweep (the last run ends at n-1)
-        if (o.run_end && lane == 0) o.run_end[r - 1] = static_cast<uint32_t>(n - 1);
+    if (last_tile) {  // publish the final table (init[s] = n - last position of s - 1: k_dc_init)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             uint2 e = pr[k * 64 + lane];
@@ -363,7 +376,7 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
                                                        const uint32_t *__restrict__ tile_run_base, const uint32_t *__restrict__ tile_syms,
                                                        const uint32_t *__restrict__ tile_set, uint32_t *__restrict__ dist,
                                                        uint8_t *__restrict__ sym, uint8_t *__restrict__ rank, uint32_t *__restrict__ run_end,
-                                                       uint32_t *__restrict__ init, uint32_t *__restrict__ final_last,
+                                                       const uint32_t *__restrict__ total_runs, uint32_t *__restrict__ final_last,
                                                        uint32_t *__restrict__ final_lrun) {
     // 8 KiB of LDS per wave, 32 KiB per workgroup: five workgroups per CU.  The tile has no padding here for that reason (the byte in
     // front of it is kept in a register).
@@ -392,7 +405,8 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
     bool wide = false;
     const bool marks = __builtin_amdgcn_readfirstlane(tile_syms[tile]) > static_cast<uint32_t>(DC_MARKS_TILE);
     stage_tile<0>(L, n, base, s, lane);
-    const uint32_t before_tile = base > 0 ? L[base - 1] : 0u;
+    const uint32_t before_tile = base > 0 ? rev_at(L, n, base - 1) : 0u;
+    const uint32_t m = __builtin_amdgcn_readfirstlane(*total_runs);  // runs of the block: a run's index in L order is m - 1 - (its index here)
     const uint32_t base32 = static_cast<uint32_t>(base);
     const uint32_t ws = base32 >= DC_WINDOW ? base32 - DC_WINDOW : 0u;  // window start (a multiple of 64)
     const uint32_t tw0 = (base32 - ws) >> 6;                             // bitmap word of the tile's first chunk
@@ -410,7 +424,7 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
     __builtin_amdgcn_wave_barrier();
     const uint32_t nsym = __builtin_amdgcn_readfirstlane(tile_syms[tile]);
     if (nsym <= 4u) {  // wave-uniform: the whole tile takes the four-symbol route
-        const FewOut fo{dist, sym, rank, run_end, init, final_last, final_lrun};
+        const FewOut fo{dist, sym, rank, run_end, final_last, final_lrun, m};
         dc_tile_few(s, before_tile, n, base, lane, nsym, __builtin_amdgcn_readfirstlane(tile_set[tile]), pr, r, tile == ntiles - 1, fo);
         return;
     }
@@ -603,6 +617,13 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
                 cnt = write_lane(rk, bit, cnt);
             }
         }
+        // ---- a symbol's first occurrence (at most one per symbol and block): its rank is the number of distinct symbols so far -- those in the table
+        //      and those first seen in this chunk in front of it (the reference's final sweep, see the head of the file)
+        for (uint64_t fz = __ballot(isB && tab.x == 0u); fz; fz &= fz - 1) {
+            const int bit = __builtin_ctzll(fz);
+            const uint32_t seen = table_after(0u) + static_cast<uint32_t>(__popcll(__ballot(first_here && tab.x == 0u) & ((1ull << bit) - 1ull)));
+            cnt = write_lane(seen, bit, cnt);
+        }
         // ---- outputs of the run-start lanes
         const uint32_t r0 = r;
         const uint32_t starts_before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(S >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(S), 0u));
@@ -610,15 +631,16 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
         const uint32_t starts_upto_w = static_cast<uint32_t>(__shfl(static_cast<int>(starts_before + (start ? 1u : 0u)), prevsame >= 0 ? prevsame : lane, 64));
         if (start) {
             const uint32_t i = base32 + static_cast<uint32_t>(j);
-            const uint32_t ridx = r0 + starts_before;
-            (sym + r0)[starts_before] = static_cast<uint8_t>(c);  // wave-uniform base + 32-bit lane offset: no per-lane 64-bit address
-            if (rank) (rank + r0)[starts_before] = static_cast<uint8_t>(cnt);
+            const uint32_t at = m - 1u - (r0 + starts_before);  // this run's index in L order: a chunk's runs are neighbours there too
+            sym[at] = static_cast<uint8_t>(c);
             // previous occurrence b (as b + 1; 0 = none) and the run it closed: lane w of this chunk, or the table's
             const uint32_t b1 = isA ? base32 + static_cast<uint32_t>(chunk * 64 + prevsame) + 1u : tab.x;
-            const uint32_t prun = isA ? r0 + starts_upto_w - 1u : tab.y - 1u;
-            if (b1) dist[prun] = i - b1 - cnt;  // = i - b - rank - 1
-            else init[c] = i;                   // first occurrence in the block
-            if (run_end && ridx > 0) run_end[ridx - 1] = i - 1;
+            dist[at] = i - b1 - cnt;  // = i - b - rank - 1; a first occurrence (b1 = 0): i - rank, the final sweep's n - b - rank - 1
+            if (rank && b1) {  // the rank found at the start of this symbol's next run in L (the run closed at b): its Context.last_rank
+                const uint32_t prun = isA ? r0 + starts_upto_w - 1u : tab.y - 1u;
+                rank[m - 1u - prun] = static_cast<uint8_t>(cnt);
+            }
+            if (run_end) run_end[at] = static_cast<uint32_t>(n - 1) - i;  // where the run ends in L
         }
         // ---- table update: the last lane of every symbol of this chunk
         __builtin_amdgcn_wave_barrier();
@@ -637,8 +659,7 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
         __builtin_amdgcn_wave_barrier();
         r += static_cast<uint32_t>(__popcll(S));
     }
-    if (tile == ntiles - 1) {  // publish the final table for the sweep (the last run ends at n-1: already in the table)
-        if (run_end && lane == 0) run_end[r - 1] = static_cast<uint32_t>(n - 1);
+    if (tile == ntiles - 1) {  // publish the final table (init[s] = n - last position of s - 1: k_dc_init)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             final_last[k * 64 + lane] = pr[k * 64 + lane].x;
@@ -647,23 +668,10 @@ __global__ __launch_bounds__(DC_BLOCK) void k_dc_main(const uint8_t *__restrict_
     }
 }
 
-// final sweep (one workgroup): every present symbol's last run end gets n - b - rank - 1, rank = place in the final MTF order
-__global__ __launch_bounds__(256) void k_dc_sweep(const uint32_t *__restrict__ final_last, const uint32_t *__restrict__ final_lrun,
-                                                   uint32_t n, uint32_t *__restrict__ dist) {
-    __shared__ uint32_t s_last[256];
-    const int c = threadIdx.x;
-    const uint32_t fp = final_last[c];
-    s_last[c] = fp;
-    __syncthreads();
-    if (!fp) return;
-    uint32_t cnt = 0;
-    for (int o = 0; o < 256; ++o) cnt += s_last[o] > fp;
-    dist[final_lrun[c] - 1] = n - fp - cnt;
-}
-
-__global__ __launch_bounds__(256) void k_fill_u32(uint32_t *p, size_t count, uint32_t v) {
-    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < count) p[i] = v;
+// init[s] = the symbol's first position in L = n - 1 - (its last position in R); n = absent (the reference's convention, src/block/dc.rs:60-66)
+__global__ __launch_bounds__(256) void k_dc_init(const uint32_t *__restrict__ final_last, uint32_t n, uint32_t *__restrict__ init) {
+    const uint32_t fp = final_last[threadIdx.x];  // (last position + 1, 0 = never seen)
+    init[threadIdx.x] = fp ? n - fp : n;
 }
 
 }  // namespace
@@ -697,16 +705,16 @@ int dc_encode_device(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t init_
         k_dc_carry_a<<<dim3(nchunks), dim3(256), 0, st>>>(tile_last, tile_lrun, tile_runs, ntiles, tpc, chunk_last, chunk_lrun);
         k_dc_carry_b<<<dim3(1), dim3(1024), 0, st>>>(chunk_last, chunk_lrun, nchunks);
         k_dc_carry_c<<<dim3(nchunks), dim3(256), 0, st>>>(tile_last, tile_lrun, ntiles, tpc, chunk_last, chunk_lrun);
-        k_fill_u32<<<dim3(1), dim3(256), 0, st>>>(d_init, 256, static_cast<uint32_t>(n));
     }
+    if (d_rank) DK_HIP(ctx, hipMemsetAsync(d_rank, 0, n, st));  // (a symbol's first run in L has rank 0: nobody writes it)
     {
         LaunchScope ls(ctx, K_DC_MAIN, 1.0 * n + 2048.0 * ntiles);
         k_dc_main<<<dim3(nblocks), dim3(DC_BLOCK), 0, st>>>(d_bwt, n, ntiles, tile_last, tile_lrun, tile_runs, tile_syms, tile_set, d_dist, d_sym, d_rank,
-                                                            d_run_end, d_init, d_final, d_final + 256);
+                                                            d_run_end, ctx->d_mail, d_final, d_final + 256);
     }
     {
         LaunchScope ls(ctx, K_DC_SWEEP, 2048.0);
-        k_dc_sweep<<<dim3(1), dim3(256), 0, st>>>(d_final, d_final + 256, static_cast<uint32_t>(n), d_dist);
+        k_dc_init<<<dim3(1), dim3(256), 0, st>>>(d_final, static_cast<uint32_t>(n), d_init);
     }
     DK_HIP(ctx, hipGetLastError());
     DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, sizeof(uint32_t), hipMemcpyDeviceToHost, st));

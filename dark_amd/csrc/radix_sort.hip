@@ -320,7 +320,10 @@ __global__ __launch_bounds__(64) void k_radix_scan(uint32_t *__restrict__ chunk_
 }
 
 // The offsets of a pass: tile_pre / chunk_base as above, chunk = tile / tiles_per_chunk.
-struct TileOffsets { const uint32_t *tile_pre; const uint32_t *chunk_base; uint32_t tiles_per_chunk; };
+// probe (tuning build, DK_SCATTER_PROBE; 0 in the product): 1 = the ranking loop does its per-wave counter read and leader write a SECOND time on a
+// second table -- same addresses, same bank conflicts, result unused: what the counters' LDS traffic costs the kernel, measured instead of argued
+// ("per-wave digit counters in registers against the 60 % LDS bank-conflict cycles"); profiles/r05_scatter_counter_probe.log
+struct TileOffsets { const uint32_t *tile_pre; const uint32_t *chunk_base; uint32_t tiles_per_chunk; int probe = 0; };
 
 // offs: where the tile's pairs of every digit go (TileOffsets).  next_digit (may be null): the digit plane for the next pass (k_radix_hist_plane).  xcd_tiles != 0: XCD-aware tile order over a grid of 8 * ceil(ntiles / 8) blocks.
 // Three workgroups per CU, not the four that registers and LDS would allow: with a fourth tile in flight per CU the L2 no longer
@@ -341,6 +344,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3 * BLOCK
     // tile-local start.  TEXT: the same 6 KiB first hold the staged codes of the tile (the counters are cleared afterwards).
     __shared__ __attribute__((aligned(16))) uint32_t s_tab[WAVES * 256 + 512];
     __shared__ uint32_t s_tmp[WAVES + 1];
+#ifdef DK_TUNING
+    __shared__ uint32_t s_probe[WAVES][256];
+#endif
     __shared__ uint8_t s_code[TEXT ? 256 : 4];
     // last pass of the suffix sort's initial sort: code -> byte for L.  From LDS: a table read from global memory made every one of a
     // thread's sixteen L stores wait for ALL its memory operations in flight, the key stores before it included (the memory counter
@@ -352,6 +358,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3 * BLOCK
     uint32_t *s_start = s_tab + WAVES * 256;
     uint32_t *s_gbase = s_start + 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef DK_TUNING
+    if (offs.probe) for (int i = tid; i < WAVES * 256; i += BLOCK) (&s_probe[0][0])[i] = 0;  // (visible behind the barriers in front of the ranking loop)
+#endif
     uint32_t tile = blockIdx.x;
     if (xcd_tiles) {
         // XCD-aware order: blocks b and b+8 share an XCD (round-robin dispatch, speed only); give every XCD one contiguous
@@ -410,6 +419,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3 * BLOCK
         if (before == 0) s_cnt[wave][d] = old + same.count();
         __builtin_amdgcn_wave_barrier();
         rnk[k] = old + before;
+#ifdef DK_TUNING
+        if (offs.probe) {  // (wave-uniform) the same two LDS accesses once more, on a table of their own
+            const uint32_t old2 = s_probe[wave][d];
+            __builtin_amdgcn_wave_barrier();
+            if (before == 0) s_probe[wave][d] = old2 + same.count();
+            __builtin_amdgcn_wave_barrier();
+            if (old2 == 0xFFFFFFFFu) rnk[k] += 1;  // (never: keeps the read alive)
+        }
+#endif
     }
     __syncthreads();
 
@@ -701,7 +719,7 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
     if (!tile_pre || !chunk_sum || !digit_total) return DK_E_NOMEM;
     hipStream_t st = ctx->stream;
     DK_HIP(ctx, hipMemsetAsync(digit_total, 0, static_cast<size_t>(npasses) * 256 * sizeof(uint32_t), st));
-    const TileOffsets offs{tile_pre, chunk_sum, cp.tiles_per_chunk};
+    const TileOffsets offs{tile_pre, chunk_sum, cp.tiles_per_chunk, DK_KNOB("DK_SCATTER_PROBE", 0)};
     int pass = 0;
     for (int shift = begin_bit; shift < end_bit; shift += 8, ++pass) {
         const bool have_plane = plane && shift > begin_bit;      // written by the previous pass

@@ -25,7 +25,7 @@ GATHER_KERNELS = {"k_round_local", "k_plateau_sort", "k_plateau_ranks", "k_bwt_g
                   "k_big_reduce", "k_big_spine", "k_big_apply", "k_big_back", "k_rerank_scan", "k_dc_carry_a", "k_dc_carry_b", "k_dc_carry_c",
                   "k_dc_runscan", "k_dc_sweep", "k_fill_u32", "k_place_active", "k_rank_active", "k_prefix_probe", "k_to_inplace",
                   "k_plateau_scan", "k_chain_ends", "k_chain_verdicts", "k_chain_apply", "k_ibwt_walk", "k_ibwt_emit", "k_ibwt_jump", "k_isa_init",
-                  "k_lf_finish", "k_lf_deep", "k_lf_straddle"}
+                  "k_lf_finish", "k_lf_deep", "k_lf_straddle", "k_lf_deep_wave", "k_lf_deep_block", "k_lf_periodic_groups", "k_lf_lce", "k_lf_list_to_arena"}
 
 # dk_stats slot (dark_amd/csrc/context.hpp) of every kernel: a slot is named after its kernel, or after the common prefix of the kernels
 # one LaunchScope brackets; bench.py reports HIP-event times per slot, the rocprofv3 CSVs are per kernel
@@ -37,7 +37,11 @@ SLOT_OF = {"k_chain_extract": "k_chain", "k_chain_ends": "k_chain", "k_chain_til
            "k_rank_active": "k_place_active", "k_to_inplace": "k_plateau_ranks", "k_plateau_count": "k_plateau_ranks",
            "k_plateau_scan": "k_plateau_ranks", "k_plateau_compact": "k_plateau_ranks",
            "k_isa_init": "k_isa_partition", "k_isa_split": "k_isa_partition",
-           "k_lf_reduce": "k_rerank_reduce", "k_lf_straddle": "k_rerank_scan", "k_lf_apply": "k_rerank_apply", "k_lf_finish": "k_round_local", "k_lf_deep": "k_chain"}
+           "k_lf_reduce": "k_rerank_reduce", "k_lf_straddle": "k_rerank_scan", "k_lf_apply": "k_rerank_apply", "k_lf_finish": "k_round_local", "k_lf_deep": "k_chain",
+           "k_lf_deep_wave": "k_chain", "k_lf_deep_block": "k_chain", "k_lf_lce": "k_chain", "k_lf_list_to_arena": "k_chain", "k_lf_periodic_groups": "k_period",
+           "k_period_first": "k_period", "k_period_spine": "k_period", "k_period_fill": "k_period", "k_period_search": "k_period", "k_period_count": "k_period",
+           "k_cls_reduce": "k_big_classify", "k_cls_spine": "k_big_classify", "k_cls_apply": "k_big_classify", "k_sort_groups": "k_radix_sort_small",
+           "k_run_probe": "k_sym_hist", "k_period_probe": "k_sym_hist"}
 
 
 def short(name):
@@ -77,7 +81,9 @@ def main():
     ap.add_argument("write_dir")
     ap.add_argument("--steps", type=int, required=True, help="steps (warm-up + timed) the profiled command ran")
     ap.add_argument("--workload", required=True)
-    ap.add_argument("--round", type=int, default=4)
+    ap.add_argument("--round", type=int, default=5)
+    ap.add_argument("--bench-line", default="", help="the JSON line the profiled command printed (kernel-trace pass): its kernel_launches_per_step -- the library's own "
+                                                     "count of bracketed launches per slot -- goes into the profile, bench.py checks later runs against it")
     args = ap.parse_args()
     fetch = collect(args.fetch_dir, "FETCH_SIZE")
     write = collect(args.write_dir, "WRITE_SIZE")
@@ -101,9 +107,16 @@ def main():
         e = slots.setdefault(v["slot"], {"hbm_bytes_per_step": 0, "launches_per_step": 0.0})
         e["hbm_bytes_per_step"] += round(v["hbm_bytes_per_launch"] * v["launches_per_step"])
         e["launches_per_step"] += v["launches_per_step"]
+    scope_launches = None
+    if args.bench_line:
+        with open(args.bench_line) as f:
+            for line in f:
+                if line.startswith("{"):
+                    scope_launches = json.loads(line).get("kernel_launches_per_step")
     json.dump({"command": "rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py "
                           "--workload %s --steps S --warmup W --no-cpu-baseline --no-decode --pipeline-blocks 0" % args.workload,
                "slots": slots,
+               "scope_launches_per_step": scope_launches,
                "workload": args.workload, "round": args.round,
                "unit_note": "counter values are KiB; FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming reads on gfx950 "
                             "(MI355X_MICROARCH.md, HBM section): fetch_corrected = 2 x raw for streaming kernels, raw for random 4-byte / "

@@ -21,7 +21,7 @@ echo "$WL FETCH_SIZE pass done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_WRITE_SIZE -- python3 $ROOT/bench.py $ARGS > $OUT/pmc_write.log 2>&1
 echo "$WL WRITE_SIZE pass done"
 cd $ROOT
-python3 tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE --steps $((STEPS + WARM + 3)) --workload $WL > $OUT/pmc_traffic.json
+python3 tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE --steps $((STEPS + WARM + 3)) --workload $WL --round ${ROUND:-5} --bench-line $OUT/bench_profiled.json > $OUT/pmc_traffic.json
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 # keep the merge small: the raw counter CSVs are large
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/stats
