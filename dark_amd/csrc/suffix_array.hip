@@ -1294,71 +1294,111 @@ __global__ __launch_bounds__(256) void k_plateau_ranks(const uint32_t *__restric
 // resolves the pair with the shortest common prefix first and needs log2(length) rounds of rank gathers for the rest.  But two suffixes
 // that start with the same symbol are ordered like the suffixes one position further on: every pair of the chain is ordered like the pair
 // behind the chain's END -- (a + K + 1, a + delta + K + 1), which is no pair any more, so its two ranks differ and decide.  One
-// comparison per chain instead of log2(length) gathers per pair:
-//   k_chain_extract  every live group of two -> a record (lower position << 32 | delta, slot of the group's head), appended in any order
-//   sort_pairs       records by lower position: the pairs of a chain become neighbours
-//   k_chain_ends     record r continues into r + 1 when that is the pair one position further on with the same delta; a record that
-//                    does not is a chain end and gets its verdict from the two ranks behind it (equal ranks = undecided: the suffixes
-//                    there sit in a bigger group; such a chain stays with the doubling rounds)
+// comparison per chain instead of log2(length) gathers per pair.  Copies of copies (two identical halves of a text that repeats itself
+// inside, three copies of a passage) leave groups of three and four: EVERY pair inside a group of at most CH_K members is a record,
+// each with its own delta, and a group is settled once all of its pairs are.
+//   k_chain_extract  every pair inside a live group of 2 .. CH_K members -> a record (delta ‖ lower position; slot of the pair's first
+//                    member; how many slots further on the second one stands, in the key's two top bits), appended in any order
+//   sort_pairs       records by (delta, lower position): the pairs of a chain become neighbours
+//   k_chain_ends     record r continues into r + 1 when that is the pair one position further on with the same delta.  Otherwise the
+//                    two ranks behind it decide.  Equal ranks there: the two suffixes sit in a bigger group together -- equal in h
+//                    symbols, so the pair h positions further on decides, and so on: a bounded walk in strides of h that ends at ranks
+//                    that differ, or beyond the next record of the same delta (then r continues into r + 1 after all: a chain runs
+//                    THROUGH the bigger groups on its way), or undecided
 //   k_chain_tiles / k_chain_spine / k_chain_verdicts   nearest chain end at or after every record (three-phase scan from the right)
-//                    -> the verdict goes to the head slot's byte
-//   k_chain_apply    slots in order: a decided pair writes both suffixes to SA (and L), gives the larger one its own rank and dies
-// Only groups of two are handled; everything else, and chains that end undecided, go on into the in-place rounds.
+//                    -> the verdict goes to the byte of the pair's first slot, in the plane of its distance
+//   k_chain_apply    slots in order: the head of a group whose pairs are all decided puts the members in order, writes them to SA (and
+//                    L), gives each its own rank and dies with them
+// Groups of more than CH_K members, and chains that end undecided, go on into the in-place rounds.
 constexpr uint8_t CH_END = 1, CH_LT = 2, CH_GT = 4;  // verdict byte: chain end | lower position is the smaller suffix | ... the larger
 constexpr int CH_TILE = 2048;
+constexpr int CH_K = 4;                   // groups of up to four members: six pairs, second member at most three slots behind the first
+constexpr int CH_WALK_THROUGH = 1024;     // strides of h through a bigger group towards the next record of the same delta
+constexpr int CH_WALK_FREE = 16;          // ... with no such record ahead
+constexpr int CH_DIST_SHIFT = 62;         // key: (distance in slots - 1) << 62 | delta << lbits | lower position; lbits <= 31
 
 // (a workgroup takes CH_EXTRACT x 256 slots and reserves its place in the record list with ONE global atomic: one per 256 slots --
 // 36 000 atomics on one address for the 9.2 M slots of the 1e8 text block -- was 0.41 ms of a kernel that reads 73 MB)
 constexpr int CH_EXTRACT = 16;
-__global__ __launch_bounds__(256) void k_chain_extract(const uint32_t *__restrict__ idx, const uint32_t *__restrict__ meta, size_t slots,
-                                                        uint64_t *__restrict__ rec_key, uint32_t *__restrict__ rec_slot, uint32_t *__restrict__ count) {
+__device__ __forceinline__ uint32_t chain_records_of(uint32_t v, uint32_t m, int kmax) {  // how many pairs does this slot open?
+    if (v & PL_DEAD_BIT) return 0u;
+    const uint32_t off = m & PL_OFF_MASK, last = (m >> PL_BITS) & PL_OFF_MASK;  // last = group size - 1
+    return (last >= 1u && last < static_cast<uint32_t>(kmax)) ? last - off : 0u;
+}
+__global__ __launch_bounds__(256) void k_chain_extract(const uint32_t *__restrict__ idx, const uint32_t *__restrict__ meta, size_t slots, int kmax, int lbits,
+                                                        uint64_t *__restrict__ rec_key, uint32_t *__restrict__ rec_slot, uint32_t cap,
+                                                        uint32_t *__restrict__ count) {  // count[0] records reserved, count[1] first reservation that did not fit
     __shared__ uint32_t s_n, s_base;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    uint64_t key[CH_EXTRACT];
-    uint32_t off[CH_EXTRACT];
-    uint32_t took = 0;  // bit c: chunk c gave this thread a record
+    uint32_t mine = 0;
 #pragma unroll
     for (int c = 0; c < CH_EXTRACT; ++c) {
         const size_t a = (static_cast<size_t>(blockIdx.x) * CH_EXTRACT + c) * 256 + threadIdx.x;
-        if (a + 1 < slots) {
-            const uint32_t v = idx[a], m = meta[a];
-            if (!(v & PL_DEAD_BIT) && (m & PL_OFF_MASK) == 0 && ((m >> PL_BITS) & PL_OFF_MASK) == 1u) {  // head of a live group of two
-                const uint32_t w = idx[a + 1] & ~PL_DEAD_BIT;
-                const uint32_t lo = v < w ? v : w, hi = v < w ? w : v;
-                key[c] = (static_cast<uint64_t>(lo) << 32) | (hi - lo);
-                off[c] = atomicAdd(&s_n, 1u);
-                took |= 1u << c;
-            }
+        if (a < slots) mine += chain_records_of(idx[a], meta[a], kmax);
+    }
+    uint32_t at = mine ? atomicAdd(&s_n, mine) : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_base = s_n ? atomicAdd(count, s_n) : 0u;
+        if (s_n && (s_base >= cap || s_n > cap - s_base)) {
+            atomicMin(count + 1, s_base);
+            s_n = 0;  // nothing of this workgroup is written: the list ends in front of it
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) s_base = s_n ? atomicAdd(count, s_n) : 0u;
-    __syncthreads();
+    if (!s_n || !mine) return;
+    at += s_base;
 #pragma unroll
     for (int c = 0; c < CH_EXTRACT; ++c) {
-        if (took & (1u << c)) {
-            rec_key[s_base + off[c]] = key[c];
-            rec_slot[s_base + off[c]] = static_cast<uint32_t>((static_cast<size_t>(blockIdx.x) * CH_EXTRACT + c) * 256 + threadIdx.x);
+        const size_t a = (static_cast<size_t>(blockIdx.x) * CH_EXTRACT + c) * 256 + threadIdx.x;
+        if (a >= slots) continue;
+        const uint32_t v = idx[a];
+        const uint32_t cnt = chain_records_of(v, meta[a], kmax);
+        for (uint32_t d = 1; d <= cnt; ++d) {
+            const uint32_t w = idx[a + d] & ~PL_DEAD_BIT;
+            const uint32_t lo = v < w ? v : w, hi = v < w ? w : v;
+            rec_key[at] = (static_cast<uint64_t>(d - 1u) << CH_DIST_SHIFT) | (static_cast<uint64_t>(hi - lo) << lbits) | lo;
+            rec_slot[at] = static_cast<uint32_t>(a);
+            ++at;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_chain_ends(const uint64_t *__restrict__ rec_key, uint32_t m, const uint32_t *__restrict__ rank, uint32_t n,
-                                                     uint8_t *__restrict__ rec_verdict) {
+__global__ __launch_bounds__(256) void k_chain_ends(const uint64_t *__restrict__ rec_key, uint32_t m, int lbits, const uint32_t *__restrict__ rank, uint32_t n,
+                                                     uint32_t h, uint8_t *__restrict__ rec_verdict) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= m) return;
-    const uint64_t k = rec_key[r];
-    const uint32_t lo = static_cast<uint32_t>(k >> 32), delta = static_cast<uint32_t>(k);
+    const uint64_t mask = (uint64_t(1) << (2 * lbits)) - 1u;
+    const uint64_t k = rec_key[r] & mask;
+    const uint32_t lo = static_cast<uint32_t>(k & ((uint64_t(1) << lbits) - 1u)), delta = static_cast<uint32_t>(k >> lbits);
     bool cont = false;
+    uint32_t gap = 0;  // the next record of this delta stands this many positions further on (0: there is none)
     if (r + 1 < m) {
-        const uint64_t k1 = rec_key[r + 1];
-        cont = static_cast<uint32_t>(k1 >> 32) == lo + 1u && static_cast<uint32_t>(k1) == delta;
+        const uint64_t k1 = rec_key[r + 1] & mask;
+        cont = k1 == k + 1u;
+        if (!cont && static_cast<uint32_t>(k1 >> lbits) == delta) gap = static_cast<uint32_t>(k1 - k);
     }
     uint8_t v = 0;
-    if (!cont) {  // the pair one position further on is no group of two with this delta: its ranks decide, unless they are equal
-        const uint32_t r_lo = rank2_of(rank, lo, n, 1u), r_hi = rank2_of(rank, lo + delta, n, 1u);
-        v = CH_END | (r_lo < r_hi ? CH_LT : r_lo > r_hi ? CH_GT : 0);
+    if (!cont) {
+        // the pair one position further on is no record: its ranks decide; while they are equal (one bigger group holds both: h symbols in common) look h further on
+        const int max_steps = gap ? CH_WALK_THROUGH : CH_WALK_FREE;
+        uint64_t off = 1;
+        v = CH_END;
+        for (int step = 0; step <= max_steps; ++step) {
+            const uint32_t o = static_cast<uint32_t>(off);
+            const uint32_t r_lo = rank2_of(rank, lo, n, o), r_hi = rank2_of(rank, lo + delta, n, o);
+            if (r_lo != r_hi) {
+                v = CH_END | (r_lo < r_hi ? CH_LT : CH_GT);
+                break;
+            }
+            off += h;
+            if (gap && off >= gap) {  // equal all the way to the next record of this delta: the chain goes on there
+                v = 0;
+                break;
+            }
+            if (off >= n) break;
+        }
     }
     rec_verdict[r] = v;
 }
@@ -1391,8 +1431,9 @@ __global__ __launch_bounds__(1024) void k_chain_spine(uint32_t *__restrict__ til
         run = max(run, v);
     }
 }
-__global__ __launch_bounds__(256) void k_chain_verdicts(const uint8_t *__restrict__ rec_verdict, const uint32_t *__restrict__ rec_slot, uint32_t m,
-                                                         const uint32_t *__restrict__ tile_max, uint8_t *__restrict__ slot_verdict) {
+__global__ __launch_bounds__(256) void k_chain_verdicts(const uint8_t *__restrict__ rec_verdict, const uint64_t *__restrict__ rec_key,
+                                                         const uint32_t *__restrict__ rec_slot, uint32_t m, const uint32_t *__restrict__ tile_max,
+                                                         uint8_t *__restrict__ planes, size_t slots) {
     __shared__ uint32_t s_tmp[4 + 1];
     const uint32_t q0 = blockIdx.x * CH_TILE + threadIdx.x * 8;
     uint32_t e[8], mine = 0;
@@ -1407,38 +1448,58 @@ __global__ __launch_bounds__(256) void k_chain_verdicts(const uint8_t *__restric
     for (int j = 0; j < 8; ++j) {
         const uint32_t q = q0 + j;
         if (q >= m) break;
-        run = max(run, e[j]);  // (the record at the right end of the list is always a chain end: run > 0)
+        run = max(run, e[j]);
+        if (!run) continue;  // (no chain end at or after this record: the list was cut short in front of one)
         const uint8_t v = rec_verdict[m - run] & (CH_LT | CH_GT);
-        if (v) slot_verdict[rec_slot[m - 1 - q]] = v;
+        if (v) planes[(rec_key[m - 1 - q] >> CH_DIST_SHIFT) * slots + rec_slot[m - 1 - q]] = v;
     }
 }
 
-// slots in order: the head of a decided pair settles both suffixes
-__global__ __launch_bounds__(256) void k_chain_apply(uint32_t *__restrict__ idx, const uint8_t *__restrict__ sym, const uint32_t *__restrict__ pos,
-                                                      const uint8_t *__restrict__ slot_verdict, size_t slots, uint32_t *__restrict__ sa,
-                                                      uint8_t *__restrict__ bwt, uint32_t *__restrict__ origin, uint32_t *__restrict__ rank) {
+// slots in order: the head of a group whose pairs are all decided settles its members.  planes[d - 1][a] = verdict of the pair (slot a, slot a + d).
+__global__ __launch_bounds__(256) void k_chain_apply(uint32_t *__restrict__ idx, const uint32_t *__restrict__ meta, const uint8_t *__restrict__ sym,
+                                                      const uint32_t *__restrict__ pos, const uint8_t *__restrict__ planes, size_t slots,
+                                                      uint32_t *__restrict__ sa, uint8_t *__restrict__ bwt, uint32_t *__restrict__ origin,
+                                                      uint32_t *__restrict__ rank) {
     const size_t a = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (a + 1 >= slots) return;
-    const uint8_t v = slot_verdict[a];
-    if (!v) return;
-    const uint32_t x = idx[a], y = idx[a + 1];
-    const bool x_first = (x < y) == (v == CH_LT);  // x is the smaller SUFFIX
-    const uint32_t p0 = pos[a], p1 = pos[a + 1];
-    const uint32_t first = x_first ? x : y, second = x_first ? y : x;
-    if (sa) {
-        sa[p0] = first;
-        sa[p1] = second;
+    if (a + 1 < slots && planes[a]) {  // (a pair of neighbouring slots has a verdict: the head of a group, or a member further in)
+        const uint32_t mt = meta[a];
+        const uint32_t g = ((mt >> PL_BITS) & PL_OFF_MASK) + 1u;
+        if ((mt & PL_OFF_MASK) == 0 && g >= 2u && g <= static_cast<uint32_t>(CH_K) && !(idx[a] & PL_DEAD_BIT)) {
+            uint32_t x[CH_K], before[CH_K];
+#pragma unroll
+            for (int i = 0; i < CH_K; ++i) {
+                x[i] = static_cast<uint32_t>(i) < g ? idx[a + i] : 0u;
+                before[i] = 0;
+            }
+            bool all = true;
+#pragma unroll
+            for (int i = 0; i < CH_K; ++i)
+#pragma unroll
+                for (int j = i + 1; j < CH_K; ++j)
+                    if (static_cast<uint32_t>(j) < g) {
+                        const uint8_t v = planes[static_cast<size_t>(j - i - 1) * slots + a + i];
+                        all = all && v != 0;
+                        const bool i_first = (x[i] < x[j]) == (v == CH_LT);  // slot i's suffix is the smaller one
+                        before[i_first ? j : i] += 1u;
+                    }
+            if (all) {
+#pragma unroll
+                for (int i = 0; i < CH_K; ++i)
+                    if (static_cast<uint32_t>(i) < g) {
+                        const uint32_t p = pos[a + before[i]];
+                        if (sa) sa[p] = x[i];
+                        if (bwt) {
+                            bwt[p] = sym[a + i];
+                            if (x[i] == 0) *origin = p;
+                        }
+                        if (before[i]) rank[x[i]] = p;  // (the smallest keeps the group's rank: the position of its head slot)
+                    }
+#pragma unroll
+                for (int i = 0; i < CH_K; ++i)
+                    if (static_cast<uint32_t>(i) < g) idx[a + i] = PL_DEAD;
+            }
+        }
     }
-    if (bwt) {
-        const uint8_t sx = sym[a], sy = sym[a + 1];
-        bwt[p0] = x_first ? sx : sy;
-        bwt[p1] = x_first ? sy : sx;
-        if (first == 0) *origin = p0;
-        if (second == 0) *origin = p1;
-    }
-    rank[second] = p1;  // (the first keeps the pair's rank: the position of its head slot)
-    idx[a] = PL_DEAD;
-    idx[a + 1] = PL_DEAD;
 }
 
 // compaction of the in-place list (when most of its slots are dead): live slots keep their order, so groups stay contiguous
@@ -2032,45 +2093,90 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
             k_to_inplace<<<dim3(div_up(slots, 256)), dim3(256), 0, st>>>(gid, gstart, slots, meta_b);
         }
         std::swap(meta_a, meta_b);  // gid was read, gid_alt written
-        // pair chains first: the groups of two that long repeats leave behind are settled by one comparison per chain
+        // pair chains first: the groups of two (three, four) that long repeats leave behind are settled by one comparison per chain
+        size_t settled_by_chains = 0;
         if (DK_KNOB("DK_PAIR_CHAINS", 1) != 0 && slots >= 2) {
             uint64_t *rec_key = keys, *rec_key_alt = keys_alt;  // (all free at this point: nothing is sorted globally any more)
             uint32_t *rec_slot = vals_3, *rec_slot_alt = pos_alt;
-            uint8_t *slot_verdict = reinterpret_cast<uint8_t *>(keys_3);
-            uint32_t *d_cnt = ctx->d_mail + 6;
+            uint8_t *planes = reinterpret_cast<uint8_t *>(keys_3);  // CH_K - 1 planes of one verdict byte per slot (3 n of the buffer's 8 n bytes) ...
+            uint8_t *rec_verdict = planes + static_cast<size_t>(CH_K - 1) * n;  // ... and one byte per record behind them
+            const int kmax = std::min(CH_K, std::max(2, DK_KNOB("DK_CHAIN_GROUP", CH_K)));
+            const int lbits = static_cast<int>(ceil_log2_u64(n));
+            const uint32_t cap = static_cast<uint32_t>(std::min<size_t>(n, 0xFFFFFFF0u));  // records the buffers hold (n each); what does not fit stays with the rounds
+            uint32_t *d_cnt = ctx->d_mail + 12;  // [0] records, [1] first reservation that did not fit
             DK_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), st));
-            DK_HIP(ctx, hipMemsetAsync(slot_verdict, 0, slots, st));
+            DK_HIP(ctx, hipMemsetAsync(d_cnt + 1, 0xFF, sizeof(uint32_t), st));
+            DK_HIP(ctx, hipMemsetAsync(planes, 0, static_cast<size_t>(kmax - 1) * slots, st));
             {
-                LaunchScope ls(ctx, K_CHAIN, 8.0 * slots);
-                k_chain_extract<<<dim3(div_up(slots, 256 * CH_EXTRACT)), dim3(256), 0, st>>>(idx_a, meta_a, slots, rec_key, rec_slot, d_cnt);
+                LaunchScope ls(ctx, K_CHAIN, 16.0 * slots);
+                k_chain_extract<<<dim3(div_up(slots, 256 * CH_EXTRACT)), dim3(256), 0, st>>>(idx_a, meta_a, slots, kmax, lbits, rec_key, rec_slot, cap, d_cnt);
             }
             DK_HIP(ctx, hipGetLastError());
-            DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 6, d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 12, d_cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             DK_HIP(ctx, hipStreamSynchronize(st));
-            const uint32_t m = ctx->h_mail[6];
-            if (trace) fprintf(stderr, "[dk] pair chains: %u groups of two among %zu slots\n", m, slots);
+            const uint32_t m = std::min(ctx->h_mail[12], ctx->h_mail[13]);
+            if (trace) fprintf(stderr, "[dk] pair chains: %u pairs inside groups of 2..%d among %zu slots%s (h = %llu)\n", m, kmax, slots, ctx->h_mail[13] != 0xFFFFFFFFu ? " (list full)" : "",
+                               static_cast<unsigned long long>(h));
             if (m > 0) {
                 route |= DK_ROUTE_PAIR_CHAINS;
-                DK_TRY(sort_pairs(ctx, rec_key, rec_key_alt, rec_slot, rec_slot_alt, m, 32, 32 + static_cast<int>(ceil_log2_u64(n))));
+                DK_TRY(sort_pairs(ctx, rec_key, rec_key_alt, rec_slot, rec_slot_alt, m, 0, 2 * lbits));
                 const size_t mark2 = ctx->ws_mark();
                 const uint32_t ntiles = static_cast<uint32_t>(div_up(m, CH_TILE));
-                uint8_t *rec_verdict = ctx->ws_alloc<uint8_t>(m);
                 uint32_t *tile_max = ctx->ws_alloc<uint32_t>(ntiles);
-                if (!rec_verdict || !tile_max) return DK_E_NOMEM;
+                if (!tile_max) return DK_E_NOMEM;
                 {
-                    LaunchScope ls(ctx, K_CHAIN, 14.0 * m + 14.0 * slots);
-                    k_chain_ends<<<dim3(div_up(m, 256)), dim3(256), 0, st>>>(rec_key, m, rank, static_cast<uint32_t>(n), rec_verdict);
+                    LaunchScope ls(ctx, K_CHAIN, 22.0 * m + 14.0 * slots);
+                    k_chain_ends<<<dim3(div_up(m, 256)), dim3(256), 0, st>>>(rec_key, m, lbits, rank, static_cast<uint32_t>(n), static_cast<uint32_t>(std::min<uint64_t>(h, n)), rec_verdict);
                     k_chain_tiles<<<dim3(ntiles), dim3(256), 0, st>>>(rec_verdict, m, tile_max);
                     k_chain_spine<<<dim3(1), dim3(1024), 0, st>>>(tile_max, ntiles);
-                    k_chain_verdicts<<<dim3(ntiles), dim3(256), 0, st>>>(rec_verdict, rec_slot, m, tile_max, slot_verdict);
-                    k_chain_apply<<<dim3(div_up(slots, 256)), dim3(256), 0, st>>>(idx_a, sym_a, pos, slot_verdict, slots, carry_bwt ? nullptr : d_sa, carry_bwt ? d_bwt : nullptr, d_origin, rank);
+                    k_chain_verdicts<<<dim3(ntiles), dim3(256), 0, st>>>(rec_verdict, rec_key, rec_slot, m, tile_max, planes, slots);
+                    k_chain_apply<<<dim3(div_up(slots, 256)), dim3(256), 0, st>>>(idx_a, meta_a, sym_a, pos, planes, slots, carry_bwt ? nullptr : d_sa, carry_bwt ? d_bwt : nullptr, d_origin, rank);
                 }
                 DK_HIP(ctx, hipGetLastError());
+                // how many slots are left?  (counted, not summed up by the kernel above: an atomic per wave on one address was 17.7 of its 18 ms on
+                // two identical halves, 1.5 of 1.6 ms on the 1e8 text block)
+                const size_t ltiles = div_up(slots, RR_TILE);
+                uint32_t *tile_live = ctx->ws_alloc<uint32_t>(ltiles);
+                if (!tile_live) return DK_E_NOMEM;
+                {
+                    LaunchScope ls(ctx, K_PLATEAU_RANKS, 4.0 * slots);
+                    k_plateau_count<<<dim3(ltiles), dim3(RR_BLOCK), 0, st>>>(idx_a, slots, tile_live);
+                    k_plateau_scan<<<dim3(1), dim3(1024), 0, st>>>(tile_live, ltiles, d_cnt);
+                }
+                DK_HIP(ctx, hipGetLastError());
+                DK_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 12, d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                DK_HIP(ctx, hipStreamSynchronize(st));
+                settled_by_chains = slots - ctx->h_mail[12];
+                if (trace) fprintf(stderr, "[dk] pair chains settled %zu of %zu slots\n", settled_by_chains, slots);
                 ctx->ws_release(mark2);
             }
         }
         unsigned launched = 0, read = 0;
-        size_t live = active;
+        size_t live = active - settled_by_chains;
+        auto compact = [&]() -> int {  // live slots keep their order, so groups stay contiguous
+            const size_t mark2 = ctx->ws_mark();
+            const size_t ntiles = div_up(slots, RR_TILE);
+            uint32_t *tile_live = ctx->ws_alloc<uint32_t>(ntiles);
+            if (!tile_live) return DK_E_NOMEM;
+            {
+                LaunchScope ls(ctx, K_PLATEAU_RANKS, 4.0 * slots + 22.0 * live);
+                k_plateau_count<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(idx_a, slots, tile_live);
+                k_plateau_scan<<<dim3(1), dim3(1024), 0, st>>>(tile_live, ntiles, d_live);
+                k_plateau_compact<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(idx_a, meta_a, sym_a, pos, slots, tile_live, idx_b, meta_b, sym_b, pos_alt);
+            }
+            DK_HIP(ctx, hipGetLastError());
+            DK_HIP(ctx, hipMemcpyAsync(h_live, d_live, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            DK_HIP(ctx, hipStreamSynchronize(st));
+            if (h_live[0] != live) return ctx->fail(DK_E_INTERNAL, "suffix_array: live count %u after compaction, expected %zu", h_live[0], live);
+            ctx->ws_release(mark2);
+            std::swap(idx_a, idx_b);
+            std::swap(meta_a, meta_b);
+            std::swap(sym_a, sym_b);
+            std::swap(pos, pos_alt);
+            slots = live;
+            launched = read = 0;
+            return DK_OK;
+        };
         auto launch_round = [&]() -> int {
             const uint32_t h_eff = static_cast<uint32_t>(std::min<uint64_t>(h, n));
             uint32_t *cnt = d_live + (launched & 7u);
@@ -2105,7 +2211,8 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
             if (trace) fprintf(stderr, "[dk] round %u (in place) slots=%zu live %zu -> %zu\n", ctx->stats.rounds - 1, slots, before, live);
             return DK_OK;
         };
-        for (;;) {
+        if (live > 0 && settled_by_chains && live * 4 <= slots && slots >= (1u << 16)) DK_TRY(compact());  // the chains left mostly dead slots behind
+        for (; live > 0;) {
             if (ctx->stats.rounds > 44) return ctx->fail(DK_E_INTERNAL, "suffix_array: no convergence after 44 rounds");
             DK_TRY(launch_round());
             if (launched - read < 2) continue;  // keep one round ahead of the host
@@ -2115,27 +2222,7 @@ int suffix_array_impl(dk_ctx *ctx, const uint8_t *d_text, size_t n, uint32_t *d_
                 // mostly dead slots: drain the round in flight, then compact (live slots keep their order: groups stay contiguous)
                 DK_TRY(read_round());
                 if (live == 0) break;
-                const size_t mark2 = ctx->ws_mark();
-                const size_t ntiles = div_up(slots, RR_TILE);
-                uint32_t *tile_live = ctx->ws_alloc<uint32_t>(ntiles);
-                if (!tile_live) return DK_E_NOMEM;
-                {
-                    LaunchScope ls(ctx, K_PLATEAU_RANKS, 4.0 * slots + 22.0 * live);
-                    k_plateau_count<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(idx_a, slots, tile_live);
-                    k_plateau_scan<<<dim3(1), dim3(1024), 0, st>>>(tile_live, ntiles, d_live);
-                    k_plateau_compact<<<dim3(ntiles), dim3(RR_BLOCK), 0, st>>>(idx_a, meta_a, sym_a, pos, slots, tile_live, idx_b, meta_b, sym_b, pos_alt);
-                }
-                DK_HIP(ctx, hipGetLastError());
-                DK_HIP(ctx, hipMemcpyAsync(h_live, d_live, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-                DK_HIP(ctx, hipStreamSynchronize(st));
-                if (h_live[0] != live) return ctx->fail(DK_E_INTERNAL, "suffix_array: live count %u after compaction, expected %zu", h_live[0], live);
-                ctx->ws_release(mark2);
-                std::swap(idx_a, idx_b);
-                std::swap(meta_a, meta_b);
-                std::swap(sym_a, sym_b);
-                std::swap(pos, pos_alt);
-                slots = live;
-                launched = read = 0;
+                DK_TRY(compact());
             }
         }
         active = 0;
