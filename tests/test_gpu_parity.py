@@ -113,6 +113,32 @@ def test_pathological_inputs(orc):
             assert first_diff(c.bwt_inverse(bwt, origin), t) is None, name
 
 
+def test_pair_chains_through_groups_of_three_and_four(orc):
+    """dk_suffix_array on copies of copies.  Two identical halves of a text that repeats itself inside leave groups of two AND of
+    four; three copies leave groups of three; more copies leave groups the chains must walk THROUGH.  Every pair inside a group of at most four
+    members is a chain record; the suffix array must equal SA-IS's, and what doubling needed log2(length of the repeat) rounds for is done in a few
+    (two identical halves: 24 rounds at 1e8 bytes before round 5, 11 since)."""
+    from dark_amd import datagen
+    base = datagen.wiki_like(1_200_000, 21)
+    inner = base.copy()
+    inner[400_000:460_000] = inner[100_000:160_000]       # a 60 KB repeat inside the text: groups of four once the text is doubled
+    five = np.concatenate([base[:300_000]] * 5)          # groups of five: no records, later chains have to walk through them
+    mixed = np.concatenate([base[:500_000], base[100_000:400_000], base[:500_000], base[200_000:450_000], datagen.wiki_like(1000, 5), base[:500_000]])
+    cases = {"two halves": (np.concatenate([base, base]), 12), "two halves with a repeat inside": (np.concatenate([inner, inner]), 12),
+             "three copies": (np.concatenate([base[:800_000]] * 3), 13), "four copies": (np.concatenate([base[:600_000]] * 4), 14),
+             "five copies": (five, 40), "copies of parts of copies": (mixed, 40),
+             "two halves, the second one cut short": (np.concatenate([base, base[:-7]]), 12), "one odd byte in front": (np.concatenate([[7], base, base]).astype(np.uint8), 12)}
+    with dark_amd.Context(max(len(t) for t, _ in cases.values())) as c:
+        for name, (t, max_rounds) in cases.items():
+            t = np.ascontiguousarray(t)
+            want = orc.sa_sais(t)
+            got = c.suffix_array(t)
+            assert first_diff(got, want) is None, (name, first_diff(got, want))
+            st = c.stats()
+            assert "pair_chains" in st["routes"], (name, st["routes"])
+            assert st["rounds"] <= max_rounds, (name, st["rounds"])
+
+
 def test_word_like_text(orc):
     """Text of a few frequent words: most suffixes sit in big groups after the initial sort, the text rounds are skipped, and the general
     rounds on ranks do the work -- the active suffixes get their head's position from the inverse permutation itself (marked SA entries),
