@@ -623,8 +623,10 @@ def main():
                         "algorithmic_bytes_per_launch": round(dk_["bytes"] / dk_["launches"], 1),
                         "measured_copy_GBs": None if copy_gbs is None else round(copy_gbs, 1),
                         "frac_of_measured_copy": None if not copy_gbs else round(achieved / copy_gbs, 4)}
-            if pmc and pmc.get("workload") == args.workload and not args.n and dom_name in pmc["kernels"]:
-                roofline["traffic"] = pmc["kernels"][dom_name]["hbm_bytes_per_launch"]
+            if pmc and pmc.get("workload") == args.workload and not args.n and (dom_name in pmc["kernels"] or dom_name in pmc.get("slots", {})):
+                # (a slot that brackets several kernels -- k_chain, k_rerank_scan -- is in the profile's "slots" table: bytes per step over its launches)
+                roofline["traffic"] = (pmc["kernels"][dom_name]["hbm_bytes_per_launch"] if dom_name in pmc["kernels"] else
+                                       round(pmc["slots"][dom_name]["hbm_bytes_per_step"] / max(1.0, pmc["slots"][dom_name]["launches_per_step"])))
                 roofline["traffic_source"] = pmc_path + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; a committed profile of this command, not this run)"
         fwd_ms = clean_acc["ms_sa"] + clean_acc["ms_bwt"]  # without the event pairs of the profiled steps (see above)
         # BWT-forward roofline the way SURVEY 8(d) defines it: min(B_fwd formula, PMC-measured HBM bytes) / t_fwd against the 8 TB/s peak
@@ -641,7 +643,7 @@ def main():
             useful = 0.0
             for kk, v in fwd_kernels.items():
                 per_step = v["hbm_bytes_per_launch"] * v["launches_per_step"]
-                if kk in ("k_bwt_gather", "k_bwt_gather_list", "k_round_local") and kk in kern:
+                if kk in ("k_bwt_gather", "k_bwt_gather_list", "k_round_local", "k_lf_finish") and kk in kern:
                     per_step = min(per_step, kern[kk]["bytes"] / k)
                 useful += per_step
             ach_u = min(b_formula, useful) / (fwd_ms * 1e-3) / 1e9

@@ -10,8 +10,8 @@ const char *kernel_slot_name(int slot) {
     // back to back carries their common prefix (k_rerank_scan = k_rerank_scan + _a + _c, see the enum)
     static const char *names[K_SLOT_COUNT] = {
         "k_sym_hist",     "k_radix_hist",  "k_radix_scan",    "k_radix_scatter", "k_rerank_reduce", "k_rerank_scan",
-        "k_rerank_apply", "k_round_local",  "k_bwt_gather",  "k_dc_summary",    "k_dc_carry",      "k_dc_main",       "k_dc_sweep",
-        "k_ibwt_hist",    "k_ibwt_lf",      "k_ibwt_walk",   "k_ibwt_jump",     "k_ibwt_emit",     "reserved",  "k_big_classify",
+        "k_rerank_apply", "k_round_local",  "k_bwt_gather",  "k_dc_summary",    "k_dc_carry",      "k_dc_main",       "k_dc_init",
+        "k_ibwt_hist",    "k_ibwt_lf",      "k_ibwt_walk",   "k_ibwt_jump",     "k_ibwt_emit",     "k_lf_finish",  "k_big_classify",
         "k_big_back",     "k_prefix_probe", "k_place_active", "k_plateau_sort", "k_plateau_ranks",
         "k_radix_sort_small", "k_radix_hist_text", "k_radix_scatter_text", "k_isa_partition", "k_isa_assemble", "k_chain", "k_period"};
     return (slot >= 0 && slot < K_SLOT_COUNT) ? names[slot] : nullptr;

@@ -30,13 +30,13 @@ enum KernelSlot : int {
     K_DC_SUMMARY,
     K_DC_CARRY,        // k_dc_runscan + k_dc_carry_a/_b/_c + k_fill_u32
     K_DC_MAIN,
-    K_DC_SWEEP,
+    K_DC_INIT,
     K_IBWT_HIST,       // k_ibwt_hist + k_ibwt_scan_a/_b/_c
     K_IBWT_LF,
     K_IBWT_WALK,
     K_IBWT_JUMP,
     K_IBWT_EMIT,
-    K_RESERVED_18,         // (k_bucket_store until round 5: the slot keeps its number)
+    K_LF_FINISH,           // k_lf_finish (slot 18: k_bucket_store's until round 5)
     K_BIG_CLASSIFY,    // k_big_reduce + k_big_spine + k_big_apply
     K_BIG_BACK,
     K_PREFIX_PROBE,

@@ -23,7 +23,7 @@
 //   k_dc_carry_*   256-way "last non-empty" exclusive scan over tiles  (last occurrence before each tile, per symbol)
 //   k_dc_main      one wave per tile, 64 positions per step (lane = position); the 256-entry last-occurrence table lives in
 //                  wave-private LDS (s_pr below), ranks are found lane-parallel, results go straight to the compact arrays
-//   k_dc_sweep     the final 256 distances
+//   k_dc_init      init[s] from the final table (the reference's sweep values come out of k_dc_main: see above)
 // Algorithmic bytes: 3 n (three reads of L) + 6 m (dist, sym, rank per run) + 2 * 2 KiB per tile of tables.
 #include "context.hpp"
 #include "device_util.hpp"
@@ -713,7 +713,7 @@ int dc_encode_device(dk_ctx *ctx, const uint8_t *d_bwt, size_t n, uint32_t init_
                                                             d_run_end, ctx->d_mail, d_final, d_final + 256);
     }
     {
-        LaunchScope ls(ctx, K_DC_SWEEP, 2048.0);
+        LaunchScope ls(ctx, K_DC_INIT, 2048.0);
         k_dc_init<<<dim3(1), dim3(256), 0, st>>>(d_final, static_cast<uint32_t>(n), d_init);
     }
     DK_HIP(ctx, hipGetLastError());

@@ -23,7 +23,7 @@ import sys
 # kernels whose reads are random narrow gathers: one 64-byte request per access, FETCH_SIZE is taken as reported
 GATHER_KERNELS = {"k_round_local", "k_plateau_sort", "k_plateau_ranks", "k_bwt_gather", "k_radix_scan",
                   "k_big_reduce", "k_big_spine", "k_big_apply", "k_big_back", "k_rerank_scan", "k_dc_carry_a", "k_dc_carry_b", "k_dc_carry_c",
-                  "k_dc_runscan", "k_dc_sweep", "k_fill_u32", "k_place_active", "k_rank_active", "k_prefix_probe", "k_to_inplace",
+                  "k_dc_runscan", "k_dc_init", "k_fill_u32", "k_place_active", "k_rank_active", "k_prefix_probe", "k_to_inplace",
                   "k_plateau_scan", "k_chain_ends", "k_chain_verdicts", "k_chain_apply", "k_ibwt_walk", "k_ibwt_emit", "k_ibwt_jump", "k_isa_init",
                   "k_lf_finish", "k_lf_deep", "k_lf_straddle", "k_lf_deep_wave", "k_lf_deep_block", "k_lf_periodic_groups", "k_lf_lce", "k_lf_list_to_arena"}
 
@@ -37,7 +37,7 @@ SLOT_OF = {"k_chain_extract": "k_chain", "k_chain_ends": "k_chain", "k_chain_til
            "k_rank_active": "k_place_active", "k_to_inplace": "k_plateau_ranks", "k_plateau_count": "k_plateau_ranks",
            "k_plateau_scan": "k_plateau_ranks", "k_plateau_compact": "k_plateau_ranks",
            "k_isa_init": "k_isa_partition", "k_isa_split": "k_isa_partition",
-           "k_lf_reduce": "k_rerank_reduce", "k_lf_straddle": "k_rerank_scan", "k_lf_apply": "k_rerank_apply", "k_lf_finish": "k_round_local", "k_lf_deep": "k_chain",
+           "k_lf_reduce": "k_rerank_reduce", "k_lf_straddle": "k_rerank_scan", "k_lf_apply": "k_rerank_apply", "k_lf_medium": "k_chain", "k_lf_deep": "k_chain",
            "k_lf_deep_wave": "k_chain", "k_lf_deep_block": "k_chain", "k_lf_lce": "k_chain", "k_lf_list_to_arena": "k_chain", "k_lf_periodic_groups": "k_period",
            "k_period_first": "k_period", "k_period_spine": "k_period", "k_period_fill": "k_period", "k_period_search": "k_period", "k_period_count": "k_period",
            "k_cls_reduce": "k_big_classify", "k_cls_spine": "k_big_classify", "k_cls_apply": "k_big_classify", "k_sort_groups": "k_radix_sort_small",
