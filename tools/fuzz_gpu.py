@@ -16,7 +16,7 @@ from oracle import orc
 def make(rng):
     n = int(rng.integers(1 << 22, 6_000_000)) if rng.random() < 0.7 else int(rng.integers(1000, 300_000))
     sigma = int(rng.choice([2, 3, 4, 5, 8, 16, 30, 64, 100, 200, 255]))
-    kind = rng.choice(["iid", "skewed", "repeats", "runs", "mixed_tiles", "periodic"])
+    kind = rng.choice(["iid", "skewed", "repeats", "runs", "mixed_tiles", "periodic", "copies"])
     alphabet = rng.choice(255, size=sigma, replace=False).astype(np.uint8)  # never 0xFF: the container cannot carry it
     if kind == "iid":
         t = alphabet[rng.integers(0, sigma, size=n)]
@@ -30,6 +30,19 @@ def make(rng):
             src = int(rng.integers(0, n - ln))
             dst = int(rng.integers(0, n - ln))
             t[dst:dst + ln] = t[src:src + ln].copy()
+    elif kind == "copies":  # whole passages two to seven times, copies of parts of copies: groups of 2 .. 7 suffixes with long common prefixes (pair chains, the walks through bigger groups)
+        p = rng.dirichlet(np.full(sigma, 0.5))
+        parts = [alphabet[rng.choice(sigma, size=max(64, n // int(rng.integers(3, 12))), p=p)]]
+        total = len(parts[0])
+        while total < n:
+            cur = np.concatenate(parts)
+            ln = int(rng.integers(1, max(2, min(len(cur), n // 2))))
+            at = int(rng.integers(0, len(cur) - ln + 1))
+            parts.append(cur[at:at + ln].copy())
+            if rng.random() < 0.5:
+                parts.append(alphabet[rng.choice(sigma, size=int(rng.integers(1, 300)), p=p)])
+            total = sum(map(len, parts))
+        t = np.concatenate(parts)[:n]
     elif kind == "runs":
         lens = rng.geometric(0.2, size=n // 3 + 10)
         syms = alphabet[rng.integers(0, sigma, size=len(lens))]
