@@ -331,12 +331,17 @@ struct TileOffsets { const uint32_t *tile_pre; const uint32_t *chunk_base; uint3
 // against 3.6 ms; two per CU: 3.65 ms but slower overall).  The kernel is bound by that, not by its ballots: a third fewer vector
 // instructions in the ranking (wave_match) did not move it.
 // BLOCK threads share the tile of RS_TILE pairs: 256 threads with 16 pairs each (three waves per SIMD), or 512 with 8 (six: DK_SCATTER_BLOCK)
-template <bool PAIRS = false, bool TEXT = false, int BLOCK = RS_BLOCK>
+// PACKED (the initial sort of at most 32 key bits where the carried code and the position fit one word: small alphabets -- 2^28 {A,C,G,T}):
+// a pair is ONE 64-bit word, (the 32 key bits) << 32 | (code of the symbol in front) << idx_bits | position; the text pass packs it, the
+// passes behind it move 8 bytes per pair instead of 12 (keys only, digits at bits 32 and up), the last one unpacks into what SortFinalOut asks for.
+struct PackedPairs { int idx_bits = 0; int key_shift = 0; };  // key_shift: where the sorted bits of the 64-bit key begin (8: a code rides in the low byte)
+template <bool PAIRS = false, bool TEXT = false, int BLOCK = RS_BLOCK, bool PACKED = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3 * BLOCK / 256, 3 * BLOCK / 256))) void k_radix_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                              const uint32_t *__restrict__ pair_lo,
                                                              uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n,
                                                              int shift, TileOffsets offs, uint32_t xcd_tiles,
-                                                             TextKeys tk, uint8_t *__restrict__ next_digit, SortFinalOut fin) {
+                                                             TextKeys tk, uint8_t *__restrict__ next_digit, SortFinalOut fin, PackedPairs pk = PackedPairs{}) {
+    static_assert(!PACKED || !PAIRS, "packed pairs are single words already");
     constexpr int WAVES = BLOCK / 64, KPT = RS_TILE / BLOCK;
     static_assert(!TEXT || BLOCK == RS_BLOCK, "the text pass builds its keys with RS_BLOCK threads");
     __shared__ uint64_t s_keys[RS_TILE];          // tile of keys in digit order; reused for the values
@@ -395,7 +400,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3 * BLOCK
         const uint32_t li = wbase + k * 64 + lane;
         if (li < valid) {
             key[k] = TEXT ? s_keys[swz(li)] : load_key<PAIRS>(kin, vin, pair_lo, tile_base + li);  // PAIRS: vin holds the high words
-            val[k] = TEXT ? static_cast<uint32_t>(tile_base + li) : (PAIRS ? 0u : vin[tile_base + li]);
+            val[k] = TEXT ? static_cast<uint32_t>(tile_base + li) : ((PAIRS || PACKED) ? 0u : vin[tile_base + li]);
+            if (PACKED && TEXT)
+                key[k] = (((key[k] >> pk.key_shift) & 0xFFFFFFFFull) << 32) | (static_cast<uint64_t>(pk.key_shift ? key[k] & 0xFFu : 0u) << pk.idx_bits) | val[k];
         } else {
             key[k] = ~0ull;  // padding sorts behind every real pair of the tile and is never written
             val[k] = 0;
@@ -467,6 +474,22 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3 * BLOCK
         const uint32_t p = k * BLOCK + tid;
         const uint64_t kk = s_keys[p];
         gi[k] = s_gbase[digit_of(kk, shift)] + p;
+        if (PACKED) {
+            if (p < valid) {
+                if (fin.vals) {  // the last pass: unpack
+                    const uint32_t lo = static_cast<uint32_t>(kk), v = lo & ((1u << pk.idx_bits) - 1u), code = lo >> pk.idx_bits;
+                    if (fin.narrow_shift >= 0) reinterpret_cast<uint32_t *>(kout)[gi[k]] = static_cast<uint32_t>(kk >> 32);
+                    else kout[gi[k]] = ((kk >> 32) << pk.key_shift) | code;
+                    vout[gi[k]] = v;
+                    if (fin.bwt) fin.bwt[gi[k]] = s_inv[code];
+                    if (fin.origin && v == 0) *fin.origin = gi[k];
+                } else {
+                    kout[gi[k]] = kk;
+                }
+                if (next_digit) next_digit[gi[k]] = static_cast<uint8_t>(digit_of(kk, shift + 8));
+            }
+            continue;
+        }
         if (p < valid) {
             if (fin.narrow_shift >= 0) reinterpret_cast<uint32_t *>(kout)[gi[k]] = static_cast<uint32_t>(kk >> fin.narrow_shift);  // SortFinalOut
             else kout[gi[k]] = kk;
@@ -474,7 +497,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3 * BLOCK
             if (fin.bwt) fin.bwt[gi[k]] = s_inv[kk & 0xFFu];  // last pass of the suffix sort's initial sort: L rides in the key's low byte
         }
     }
-    if (PAIRS) return;  // keys only
+    if (PAIRS || PACKED) return;  // keys only
     __syncthreads();
     uint32_t *s_vals = reinterpret_cast<uint32_t *>(s_keys);
 #pragma unroll
@@ -720,8 +743,14 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
     hipStream_t st = ctx->stream;
     DK_HIP(ctx, hipMemsetAsync(digit_total, 0, static_cast<size_t>(npasses) * 256 * sizeof(uint32_t), st));
     const TileOffsets offs{tile_pre, chunk_sum, cp.tiles_per_chunk, DK_KNOB("DK_SCATTER_PROBE", 0)};
+    // packed pairs (PackedPairs above): the initial sort of at most 32 key bits whose carried code and position share a 32-bit word
+    const int idx_bits = static_cast<int>(ceil_log2_u64(count));
+    const bool packed = text && final_out && final_out->vals && end_bit - begin_bit <= 32 && end_bit - begin_bit > 8 && (begin_bit == 0 || begin_bit == 8) &&
+                        (begin_bit ? text->bits : 0) + idx_bits <= 32 && DK_KNOB("DK_PACKED_SORT", 1) != 0;
+    const PackedPairs pk{idx_bits, begin_bit};
     int pass = 0;
     for (int shift = begin_bit; shift < end_bit; shift += 8, ++pass) {
+        const int pshift = 32 + (shift - begin_bit);  // where the digit of this pass stands in a packed pair
         const bool have_plane = plane && shift > begin_bit;      // written by the previous pass
         uint8_t *emit = plane && shift + 8 < end_bit ? plane : nullptr;  // read by the next one
         const TextKeys *tk = text && shift == begin_bit ? text : nullptr;
@@ -737,7 +766,7 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
             else if (have_plane)
                 k_radix_hist<HS_PLANE><<<grid, block, 0, st>>>(nullptr, nullptr, nullptr, plane, count, shift, cp.ntiles, cp.tiles_per_chunk, tile_pre, chunk_sum, totals, TextKeys{});
             else
-                k_radix_hist<HS_KEYS><<<grid, block, 0, st>>>(keys, nullptr, nullptr, nullptr, count, shift, cp.ntiles, cp.tiles_per_chunk, tile_pre, chunk_sum, totals, TextKeys{});
+                k_radix_hist<HS_KEYS><<<grid, block, 0, st>>>(keys, nullptr, nullptr, nullptr, count, packed ? pshift : shift, cp.ntiles, cp.tiles_per_chunk, tile_pre, chunk_sum, totals, TextKeys{});
         }
         {
             LaunchScope ls(ctx, K_RADIX_SCAN, 2.0 * 1024.0 * cp.nchunks);
@@ -746,10 +775,17 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
         if (fin.bucket_starts)  // the first chunk's row: pairs with a smaller digit = where every digit's pairs start
             DK_HIP(ctx, hipMemcpyAsync(fin.bucket_starts, chunk_sum, 256 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
         {
-            LaunchScope ls(ctx, tk ? K_RADIX_SCATTER_TEXT : K_RADIX_SCATTER, ((tk ? 13.0 : 24.0) + (emit ? 1.0 : 0.0) + (fin.bwt ? 1.0 : 0.0) - (fin.narrow_shift >= 0 ? 4.0 : 0.0)) * count);
+            LaunchScope ls(ctx, tk ? K_RADIX_SCATTER_TEXT : K_RADIX_SCATTER,
+                           ((packed ? (tk ? 9.0 : last ? 20.0 : 16.0) : tk ? 13.0 : 24.0) + (emit ? 1.0 : 0.0) + (fin.bwt ? 1.0 : 0.0) - (fin.narrow_shift >= 0 ? 4.0 : 0.0)) * count);
             const bool xcd = DK_KNOB("DK_XCD", 1) != 0;
             const size_t grid = xcd ? 8 * div_up(ntiles, 8) : ntiles;
-            if (tk)
+            if (packed && tk)
+                k_radix_scatter<false, true, RS_BLOCK, true><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(nullptr, nullptr, nullptr, keys_alt, vout, count, pshift, offs,
+                                                                                                  xcd ? static_cast<uint32_t>(ntiles) : 0u, *tk, emit, fin, pk);
+            else if (packed)
+                k_radix_scatter<false, false, RS_BLOCK, true><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(keys, nullptr, nullptr, keys_alt, vout, count, pshift, offs,
+                                                                                                   xcd ? static_cast<uint32_t>(ntiles) : 0u, TextKeys{}, emit, fin, pk);
+            else if (tk)
                 k_radix_scatter<false, true><<<dim3(grid), dim3(RS_BLOCK), 0, st>>>(nullptr, nullptr, nullptr, keys_alt, vout, count, shift, offs,
                                                                                    xcd ? static_cast<uint32_t>(ntiles) : 0u, *tk, emit, fin);
             else if (DK_KNOB("DK_SCATTER_BLOCK", DK_SCATTER_BLOCK_DEFAULT) == 512)
@@ -761,7 +797,7 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
         }
         DK_HIP(ctx, hipGetLastError());
         std::swap(keys, keys_alt);
-        if (!fin.vals) std::swap(vals, vals_alt);  // (the last pass wrote the values to their final home: both ping-pong buffers are free)
+        if (!fin.vals && !packed) std::swap(vals, vals_alt);  // (the last pass wrote the values to their final home: both ping-pong buffers are free)
         ctx->stats.sort_passes += 1;
         ctx->stats.sorted_elements += count;
     }
