@@ -51,7 +51,7 @@ def short(name):
     k = m.group(1)
     # the first pass of the initial sort is its own template instance (keys from the text) and its own dk_stats slot
     args = m.group(2).replace(" ", "") if m.group(2) else ""
-    if (k == "k_radix_scatter" and args == "<false,true>") or (k == "k_radix_hist" and args == "<3>"):  # HS_TEXT = 3
+    if (k == "k_radix_scatter" and args.startswith("<false,true")) or (k == "k_radix_hist" and args == "<3>"):  # <PAIRS, TEXT, BLOCK, PACKED>; HS_TEXT = 3
         k += "_text"
     return k
 
