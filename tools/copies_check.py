@@ -1,4 +1,5 @@
-"""scratch: dk_suffix_array on two identical halves (and three thirds, and copies of copies): time, rounds, check against the oracle."""
+"""dk_suffix_array on two identical halves, three identical thirds and a block put together from copies of copies: time, rounds, route; with the
+oracle's suffix array beside it unless `nocheck` is given.   python tools/copies_check.py [bytes per half, default 5e7] [nocheck]"""
 import os, sys, time, json
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch, dark_amd

@@ -1,3 +1,5 @@
+"""Warm-up for a launch timeline of one workload's suffix sort + BWT: run under DK_TRACE=1 DK_TRACE_LAUNCHES=1 on the tuning build (DARK_AMD_LIB), every
+bracketed launch is printed with its slot, stream and time.   python tools/launch_timeline.py [workload, default realtext_5e7]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch, dark_amd

@@ -1,3 +1,5 @@
+"""Per-kernel-slot times of one dk_suffix_array call (the suffix-array path, no L-first): python tools/sa_kernel_breakdown.py halves|thirds|text|tile
+(two identical 50 MB halves, three thirds, the 1e8 text block; `tile`: the BWT route of the tile-crossing-groups test shape, with DK_TRACE on the tuning build)"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch, dark_amd
