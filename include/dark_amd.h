@@ -211,7 +211,7 @@ typedef struct dk_stats {
 #define DK_ROUTE_GENERAL_ROUND 0x40u    /* a doubling round in its general form ran */
 #define DK_ROUTE_BIG_GROUPS 0x80u       /* ... with groups of more than 1024 members through the global sort */
 #define DK_ROUTE_INPLACE_ROUNDS 0x100u  /* in-place (plateau) rounds ran */
-#define DK_ROUTE_PAIR_CHAINS 0x200u     /* ... after pair chains settled groups of two */
+#define DK_ROUTE_PAIR_CHAINS 0x200u     /* ... after pair chains settled groups of two to four */
 #define DK_ROUTE_LFIRST 0x400u          /* BWT callers: only groups with different symbols in front were refined (no suffix array) */
 #define DK_ROUTE_LFIRST_BIG_ROUND 0x800u  /* ... with at least one global-sort round of big groups */
 #define DK_ROUTE_LFIRST_DEEP 0x1000u    /* ... and groups that went the way of long repeats (common extension measured directly) */
