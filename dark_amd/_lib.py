@@ -25,7 +25,7 @@ class Stats(C.Structure):
                 ("ws_peak_bytes", C.c_uint64), ("ws_size_bytes", C.c_uint64)]
 ROUTES = {"short_prefix": 0x1, "narrow_keys": 0x2, "text_round": 0x4, "isa_windows": 0x8, "isa_marked": 0x10, "isa_buckets": 0x20,
           "general_round": 0x40, "big_groups": 0x80, "inplace_rounds": 0x100, "pair_chains": 0x200, "lfirst": 0x400,
-          "lfirst_big_round": 0x800, "lfirst_deep": 0x1000, "lfirst_fallback": 0x2000, "lfirst_giant": 0x4000, "period_round": 0x8000}
+          "lfirst_big_round": 0x800, "lfirst_deep": 0x1000, "lfirst_fallback": 0x2000, "lfirst_giant": 0x4000, "period_round": 0x8000, "packed_pairs": 0x10000}
 
 
 # every symbol include/dark_amd.h declares: name -> (restype, argtypes)

@@ -42,7 +42,19 @@ void *dk_ctx::ws_try_alloc_bytes(size_t bytes) {
     void *p = ws + ws_used;
     ws_used += aligned;
     if (ws_used > ws_peak) ws_peak = ws_used;
+    ws_poison(p, aligned);
     return p;
+}
+
+// tuning build, DK_POISON=<byte>: every allocation from the workspace is filled with that byte first -- a read of memory nobody has written
+// gives the same wrong answer every time instead of depending on what the previous call left behind
+void dk_ctx::ws_poison(void *p, size_t bytes) {
+#ifdef DK_TUNING
+    static const int pattern = dk::tuning_knob("DK_POISON", -1);
+    if (pattern >= 0) (void)hipMemsetAsync(p, pattern & 0xFF, bytes, stream);
+#else
+    (void)p; (void)bytes;
+#endif
 }
 
 void *dk_ctx::ws_alloc_bytes(size_t bytes) {
@@ -55,6 +67,7 @@ void *dk_ctx::ws_alloc_bytes(size_t bytes) {
     void *p = ws + ws_used;
     ws_used += aligned;
     if (ws_used > ws_peak) ws_peak = ws_used;
+    ws_poison(p, aligned);
     return p;
 }
 

@@ -108,6 +108,7 @@ struct dk_ctx {
     template <class T> T *ws_alloc(size_t count) { return static_cast<T *>(ws_alloc_bytes(count * sizeof(T))); }
     // the same for OPTIONAL buffers (a faster variant that can be done without): nullptr when it does not fit, no error recorded
     void *ws_try_alloc_bytes(size_t bytes);
+    void ws_poison(void *p, size_t bytes);  // tuning build: DK_POISON
     template <class T> T *ws_try_alloc(size_t count) { return static_cast<T *>(ws_try_alloc_bytes(count * sizeof(T))); }
     size_t ws_mark() const { return ws_used; }
     void ws_release(size_t mark) { ws_used = mark; }

@@ -748,6 +748,7 @@ static int sort_pairs_classic(dk_ctx *ctx, uint64_t *&keys, uint64_t *&keys_alt,
     const bool packed = text && final_out && final_out->vals && end_bit - begin_bit <= 32 && end_bit - begin_bit > 8 && (begin_bit == 0 || begin_bit == 8) &&
                         (begin_bit ? text->bits : 0) + idx_bits <= 32 && DK_KNOB("DK_PACKED_SORT", 1) != 0;
     const PackedPairs pk{idx_bits, begin_bit};
+    if (packed) ctx->stats.sa_route |= DK_ROUTE_PACKED_PAIRS;
     int pass = 0;
     for (int shift = begin_bit; shift < end_bit; shift += 8, ++pass) {
         const int pshift = 32 + (shift - begin_bit);  // where the digit of this pass stands in a packed pair

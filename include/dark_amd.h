@@ -218,6 +218,7 @@ typedef struct dk_stats {
 #define DK_ROUTE_LFIRST_GIANT 0x4000u    /* ... and common extensions longer than 64 KiB, measured by the whole grid (copies of whole files) */
 #define DK_ROUTE_LFIRST_FALLBACK 0x2000u  /* the L-first path gave up (giant groups / over-long common extensions): suffix-array path from the start */
 #define DK_ROUTE_PERIOD_ROUND 0x8000u    /* a period round ran: suffixes inside stretches of one short period (runs, (ab)^n, zero padding) placed by where the stretch ends */
+#define DK_ROUTE_PACKED_PAIRS 0x10000u   /* the initial sort moved packed pairs: key, carried code and position in one 64-bit word (at most 32 key bits, small alphabets) */
 /* enable (1) / disable (0) HIP-event bracketing of every kernel launch on the context's stream */
 int dk_set_profiling(dk_ctx *ctx, int enabled);
 int dk_stats_reset(dk_ctx *ctx);

@@ -68,8 +68,8 @@ def test_five_megabyte_blocks(orc):
              np.concatenate([datagen.wiki_like(n // 2, 10)] * 2), _fib_word(n)]
     # what each case must have gone through: (suffix array call, BWT call)
     routes = [({"isa_windows", "text_round", "inplace_rounds", "pair_chains"}, {"lfirst", "lfirst_deep"}),   # text: long repeats end as pair chains / deep groups
-              ({"short_prefix", "narrow_keys", "text_round"}, {"short_prefix", "narrow_keys"}),              # {A,C,G,T}: the probe shortens the key
-              ({"short_prefix", "narrow_keys"}, {"short_prefix", "narrow_keys"}),                            # random bytes
+              ({"short_prefix", "narrow_keys", "text_round", "packed_pairs"}, {"short_prefix", "narrow_keys", "packed_pairs"}),  # {A,C,G,T}: the probe shortens the key; 32 key bits + position in one word
+              ({"short_prefix", "narrow_keys", "packed_pairs"}, {"short_prefix", "narrow_keys", "packed_pairs"}),                # random bytes (5 MB: code 8 bits + position 23)
               ({"period_round", "big_groups"}, {"period_round"}),                                             # period 2: one round on the tokens of the stretch's end
               ({"isa_windows", "inplace_rounds"}, {"lfirst", "lfirst_deep"}),                                 # two identical halves
               ({"isa_windows", "isa_marked", "general_round", "big_groups"}, {"general_round"})]              # Fibonacci word (repetitive, no period to find): giant groups, doubling
@@ -251,6 +251,26 @@ def test_tile_boundaries(ctx, orc):
             got = ctx.dc_encode(bwt)
             for key in ("init", "d", "sym", "rank"):
                 assert first_diff(got[key], want[key]) is None, ("dc." + key, n, first_diff(got[key], want[key]))
+
+
+def test_first_call_of_a_fresh_context(orc):
+    """A context's very first call, on a tiny block, right after creation -- forty times.  dk_ctx_create used to clear the mailbox with a memset on the
+    null stream, which does not order the context's non-blocking stream: the first call's symbol histogram could be wiped after its kernel had written it
+    (one symbol "seen" -> the suffix array of a^n), one run in four where a big context had been destroyed just before (round 5)."""
+    from dark_amd import datagen
+    with dark_amd.Context(5_000_011) as big:
+        big.suffix_array(datagen.random_bytes(5_000_011, 9))
+    rng = np.random.default_rng(53)
+    t = rng.integers(0, 3, size=2047, dtype=np.uint8)
+    want = orc.sa_sais(t)
+    wb, wo = orc.bwt_forward(t, want)
+    for k in range(40):
+        with dark_amd.Context(1 << 20) as c:
+            if k & 1:
+                bwt, origin = c.bwt_forward(t)
+                assert origin == wo and first_diff(bwt, wb) is None, k
+            else:
+                assert first_diff(c.suffix_array(t), want) is None, k
 
 
 def test_errors_and_limits(ctx):
