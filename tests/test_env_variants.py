@@ -7,6 +7,7 @@ product library has them compiled in as constants:
   DK_BWT_CARRY=0 L gathered from the suffix array instead of riding with the suffixes | DK_PREFIX=0|1|2|3 prefix length of the initial sort
   DK_LF_MEDIUM=0 the L-first path's big list as one region through the global sort (default: groups of up to 8192 members sorted inside LDS)
   DK_CHAIN_GROUP=2|3 pair chains for groups of at most two / three members | DK_LF_SHORT_SLOTS / _STEPS, DK_LF_STEPS / _STUCK the step limits of k_lf_finish
+  DK_POISON=<byte> every workspace allocation is filled with that byte first (a read of memory nobody wrote fails every time, not once in a while)
   DK_PACKED_SORT=0 the initial sort of at most 32 key bits moves (key, position) pairs, not packed words
   DK_LF_FORK / _REFORK when the deep groups are ordered beside the rounds (0: only at the end) | DK_LF_WAVE=0 no wave kernel | DK_LF_TAIL groups of a short big list end inside LDS
   DK_PERIOD=0 never a period round | 2 a period round wherever the probe finds one periodic 64-byte window (the product asks for an eighth of the block)"""
@@ -165,7 +166,8 @@ def test_entropy_error_paths_return_codes(threads):
                                  {"DK_LF_SWITCH": "100"}, {"DK_LF_MEDIUM": "0"}, {"DK_LFIRST": "2", "DK_LF_MEDIUM": "0"},
                                  {"DK_CHAIN_GROUP": "2"}, {"DK_CHAIN_GROUP": "3"}, {"DK_LF_SHORT_SLOTS": "0"}, {"DK_LF_SHORT_SLOTS": "100000000", "DK_LF_SHORT_STEPS": "2"},
                                  {"DK_LF_FORK": "0"}, {"DK_LF_FORK": "100000000", "DK_LF_REFORK": "64"}, {"DK_LF_WAVE": "0"}, {"DK_LF_TAIL": "1000000"},
-                                 {"DK_LF_STEPS": "2", "DK_LF_STUCK": "1"}, {"DK_PACKED_SORT": "0"}, {"DK_PACKED_SORT": "1", "DK_NARROW_KEYS": "0"}])
+                                 {"DK_LF_STEPS": "2", "DK_LF_STUCK": "1"}, {"DK_PACKED_SORT": "0"}, {"DK_PACKED_SORT": "1", "DK_NARROW_KEYS": "0"},
+                                 {"DK_POISON": "165"}, {"DK_POISON": "255", "DK_LFIRST": "2"}])
 def test_gpu_variants_match_oracle(env):
     _run(GPU_SNIPPET, env, tuning=True)
 

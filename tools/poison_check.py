@@ -31,6 +31,13 @@ with dark_amd.Context(1 << 20) as ctx:
             wb, wo = orc.bwt_forward(t, want)
             bwt, origin = ctx.bwt_forward(t)
             ok_sa = bool((got == want).all()); ok_bwt = origin == wo and bool((np.frombuffer(bwt, np.uint8) == np.frombuffer(wb, np.uint8)).all())
+            if ok_bwt and rep == 0:  # the stages behind the BWT as well: inverse, distance coding, the coded block both ways
+                back = ctx.bwt_inverse(bwt, origin)
+                dc_w, dc_g = orc.dc_encode(wb), ctx.dc_encode(bwt)
+                ok_bwt = bytes(back) == t.tobytes() and all((np.asarray(dc_g[k]) == np.asarray(dc_w[k])).all() for k in ("init", "d", "sym", "rank"))
+                if len(np.unique(t)) > 1 and not (t == 255).any():
+                    stream = ctx.block_encode("dark", t)
+                    ok_bwt = ok_bwt and stream == orc.block_dc_encode("dark", t) and bytes(ctx.block_decode("dark", stream, len(t))) == t.tobytes()
             if not (ok_sa and ok_bwt):
                 bad += 1
                 d = np.flatnonzero(got != want)
