@@ -23,6 +23,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver of these boxes supports dmabuf IPC only: without this RCCL's first collective fails with hipIpcGetMemHandle (the image exports it;
+# a launcher that scrubs the environment would not)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
 
